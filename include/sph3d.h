@@ -1,0 +1,183 @@
+/* sph3d.h — C ABI of libsph3d (hand-written HIP kernels for gfx950 / MI355X).
+ *
+ * Drop-in boundary for the SPH3D-GCN tf_ops hot path.  Each entry point
+ * replaces ONE launcher of the reference (cited per function) and takes
+ * exactly what that launcher took — plain ints/floats by value and raw DEVICE
+ * pointers — plus a HIP stream.  Differences from the reference launchers, all
+ * deliberate:
+ *   - every call returns an int status (0 = ok, <0 = SPH3D_E*); the reference
+ *     returned void and never checked a launch;
+ *   - every call is stream-ordered on `stream` (hipStream_t passed as void*);
+ *     nothing synchronises the device (the reference's pool/unpool launchers
+ *     called cudaDeviceSynchronize, tf_pool3d_gpu.cu:97,104,111,118);
+ *   - outputs do NOT need to be pre-zeroed by the caller: each op fully
+ *     defines its outputs (unused neighbour slots = 0, as the reference's
+ *     cudaMemset in OpKernel::Compute left them, e.g. tf_nnquery.cpp:100-102);
+ *   - all tensors are dense row-major float32 / int32, as in the reference.
+ *
+ * Notation: B batch, N database/input points, M query/output points,
+ * K = nn_sample cap, C in-channels, r depth multiplier, F = n*p*q+1 bins.
+ *
+ * No torch / TF types appear here.  The Python ops in sph3d_gcn_amd/ bind this
+ * file with ctypes; INTEGRATION.md shows the equivalent TF OpKernel binding.
+ */
+#ifndef SPH3D_H
+#define SPH3D_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sph3d_stream_t;   /* hipStream_t */
+
+enum {
+    SPH3D_OK = 0,
+    SPH3D_EINVAL = -1,      /* bad dimension / attribute (what OP_REQUIRES rejected) */
+    SPH3D_EWORKSPACE = -2,  /* workspace too small */
+    SPH3D_ELAUNCH = -3,     /* hipGetLastError() != hipSuccess after launch */
+    SPH3D_EUNSUPPORTED = -4 /* shape outside what the kernels are built for */
+};
+
+/* Library identification. */
+int sph3d_abi_version(void);                 /* currently 1 */
+const char* sph3d_last_error(void);          /* thread-local text of the last non-OK status */
+const char* sph3d_build_info(void);          /* "gfx950 hipcc <ver> ..." */
+
+/* ---- nnquery ------------------------------------------------------------
+ * replaces buildSphereNeighborLauncher (tf_ops/nnquery/tf_nnquery_gpu.cu:115-121;
+ * kernel cal_nn_binidx :15-65; op BuildSphereNeighbor tf_nnquery.cpp:55-111).
+ * database[B,N,3], query[B,M,3] -> nn_index[B,M,K] i32 (ascending database
+ * index, first K win, unused = 0), nn_count[B,M] i32 in [1,K],
+ * nn_dist[B,M,K] f32 = sqrt(euclidean distance) (sic, :47,:54).
+ * Reference semantics reproduced bit-exactly, including the radius-growth
+ * chain (:59): query (i,j) is searched with the radius left behind by the
+ * previous query of reference-thread (i mod 32, j mod 1024).
+ * Growth is bounded: after SPH3D_MAX_GROWTH_PASSES empty passes the query is
+ * stored with nn_count = 0 (the reference would spin forever). */
+#define SPH3D_MAX_GROWTH_PASSES 4096
+int sph3d_build_sphere_neighbor(int B, int N, int M, int nn_sample, float radius,
+                                const float* database, const float* query,
+                                int* nn_index, int* nn_count, float* nn_dist,
+                                sph3d_stream_t stream);
+
+/* replaces buildCubeNeighborLauncher (tf_nnquery_gpu.cu:123-127; kernel
+ * cal_nn_binidx_cube :72-113; op BuildCubeNeighbor tf_nnquery.cpp:116-168).
+ * -> nn_index[B,M,K,2] i32 = (database index, cubic bin id), nn_count[B,M]. */
+int sph3d_build_cube_neighbor(int B, int N, int M, int grid_size, int nn_sample, float length,
+                              const float* database, const float* query,
+                              int* nn_index, int* nn_count,
+                              sph3d_stream_t stream);
+
+/* ---- buildkernel --------------------------------------------------------
+ * replaces sphericalKernelLauncher (tf_ops/buildkernel/tf_buildkernel_gpu.cu:83-89;
+ * kernel build_spherical_kernel :20-79; op SphericalKernel tf_buildkernel.cpp:35-99).
+ * -> filt_index[B,M,K] i32: 0 = self / unused slot, else
+ * 1 + nID + n*pID + n*p*qID.  Requires n>2 even, p>0 even, q>0 (:39-49).
+ * atan2f is include/sph3d_atan2f.h on device and in the oracle. */
+int sph3d_spherical_kernel(int B, int N, int M, int K, int n, int p, int q, float radius,
+                           const float* database, const float* query,
+                           const int* nn_index, const int* nn_count, const float* nn_dist,
+                           int* filt_index,
+                           sph3d_stream_t stream);
+
+/* ---- convolution --------------------------------------------------------
+ * replaces depthwiseConv3dLauncher (tf_ops/convolution/tf_conv3d_gpu.cu:107-113;
+ * kernel depthwise_conv3d_forward :7-29; op DepthwiseConv3d tf_conv3d.cpp:47-94).
+ * out[b,m,c*r+rho] = (1/cnt) * sum_k in[b,idx_k,c] * filt[bin_k,c,rho].
+ * F (= filter.shape[0]) is an extra argument: the filter table is staged in LDS. */
+int sph3d_depthwise_conv3d(int B, int N, int M, int F, int C, int r, int K,
+                           const int* nn_index, const int* nn_count, const int* bin_index,
+                           const float* input, const float* filter, float* output,
+                           sph3d_stream_t stream);
+
+/* replaces depthwiseConv3dGradLauncher (tf_conv3d_gpu.cu:115-140; kernels
+ * depthwise_input_backward :32-55, depthwise_filter_backward :58-101;
+ * op DepthwiseConv3dGrad tf_conv3d.cpp:101-158).
+ * grad_input[B,N,C], grad_filter[F,C,r] are fully written (zeroed inside).
+ * workspace: sph3d_depthwise_conv3d_grad_workspace() bytes of device memory
+ * (may be 0 / NULL when that function returns 0). */
+size_t sph3d_depthwise_conv3d_grad_workspace(int B, int N, int M, int F, int C, int r, int K);
+int sph3d_depthwise_conv3d_grad(int B, int N, int M, int F, int C, int r, int K,
+                                const int* nn_index, const int* nn_count, const int* bin_index,
+                                const float* input, const float* filter, const float* grad_output,
+                                float* grad_input, float* grad_filter,
+                                void* workspace, size_t workspace_bytes,
+                                sph3d_stream_t stream);
+
+/* ---- pooling ------------------------------------------------------------
+ * replaces maxPool3dLauncher / maxPool3dGradLauncher / avgPool3dLauncher /
+ * avgPool3dGradLauncher (tf_ops/pooling/tf_pool3d_gpu.cu:93-119; kernels :5-90;
+ * ops tf_pool3d.cpp:63-234).  max_index[B,M,C] holds the argmax POINT id
+ * (first maximum wins, strict >). */
+int sph3d_max_pool3d(int B, int N, int M, int C, int K,
+                     const int* nn_index, const int* nn_count, const float* input,
+                     float* output, int* max_index, sph3d_stream_t stream);
+int sph3d_max_pool3d_grad(int B, int N, int M, int C,
+                          const int* max_index, const float* grad_output,
+                          float* grad_input, sph3d_stream_t stream);
+int sph3d_avg_pool3d(int B, int N, int M, int C, int K,
+                     const int* nn_index, const int* nn_count, const float* input,
+                     float* output, sph3d_stream_t stream);
+int sph3d_avg_pool3d_grad(int B, int N, int M, int C, int K,
+                          const int* nn_index, const int* nn_count, const float* grad_output,
+                          float* grad_input, sph3d_stream_t stream);
+
+/* ---- unpooling ----------------------------------------------------------
+ * replaces meanInterpolateLauncher / meanInterpolateGradLauncher /
+ * weightedInterpolateLauncher / weightedInterpolateGradLauncher
+ * (tf_ops/unpooling/tf_unpool3d_gpu.cu:87-113; kernels :5-84; ops
+ * tf_unpool3d.cpp:64-242).  Here N = fine/output count, M = coarse/input
+ * count (the reference's naming): input[B,M,C], nn_index[B,N,K] -> output[B,N,C]. */
+int sph3d_mean_interpolate(int B, int N, int M, int C, int K,
+                           const int* nn_index, const int* nn_count, const float* input,
+                           float* output, sph3d_stream_t stream);
+int sph3d_mean_interpolate_grad(int B, int N, int M, int C, int K,
+                                const int* nn_index, const int* nn_count, const float* grad_output,
+                                float* grad_input, sph3d_stream_t stream);
+int sph3d_weighted_interpolate(int B, int N, int M, int C, int K,
+                               const int* nn_index, const int* nn_count,
+                               const float* input, const float* weight,
+                               float* output, sph3d_stream_t stream);
+int sph3d_weighted_interpolate_grad(int B, int N, int M, int C, int K,
+                                    const int* nn_index, const int* nn_count,
+                                    const float* grad_output, const float* weight,
+                                    float* grad_input, sph3d_stream_t stream);
+
+/* ---- sampling -----------------------------------------------------------
+ * replaces farthestPointSampleLauncher (tf_ops/sampling/tf_sample_gpu.cu:77-80;
+ * kernel farthestpointsampleKernel :7-73; op FarthestPointSample tf_sample.cpp:30-58).
+ * inp[b,n,3] -> out[b,m] i32; index 0 first, then argmax of the running
+ * minimum squared distance; ties: lower (k mod 1024) wins, then lower k
+ * (the reference's thread/tree order, :49,:56-66).  Race-free (the reference
+ * has a latent race at :68).
+ * workspace: sph3d_farthest_point_sample_workspace(b,n,m) bytes (0 when the
+ * cloud fits the register-resident kernel, n <= 16384). */
+size_t sph3d_farthest_point_sample_workspace(int b, int n, int m);
+int sph3d_farthest_point_sample(int b, int n, int m, const float* inp, int* out,
+                                void* workspace, size_t workspace_bytes,
+                                sph3d_stream_t stream);
+
+/* ---- pointwise 1x1 feature GEMM (fp32 MFMA) -----------------------------
+ * replaces the tf.matmul inside separable_conv3d / pointwise_conv3d /
+ * fully_connected (utils/sph3gcn_util.py:146-150, 204-206, 260) -> cuBLAS SGEMM
+ * in the reference.  Y[R,Cout] = X[R,Cin] * W[Cin,Cout] (+ bias[Cout]) with an
+ * optional fused ELU; exact fp32 (v_mfma_f32_32x32x2_f32).
+ * act: 0 = none, 1 = ELU.  bias may be NULL.
+ * trans_x / trans_w select the backward products:
+ *   dX[R,Cin]  = dY[R,Cout] * W^T      -> sph3d_pointwise_gemm(R, Cout, Cin, dY, W, trans_w=1)
+ *   dW[Cin,Cout] = X^T[Cin,R] * dY     -> sph3d_pointwise_gemm_tn(...) */
+int sph3d_pointwise_gemm(int R, int Cin, int Cout,
+                         const float* X, const float* W, const float* bias, int act,
+                         int trans_w, float* Y, sph3d_stream_t stream);
+int sph3d_pointwise_gemm_tn(int R, int Cin, int Cout,
+                            const float* X, const float* dY, float* dW,
+                            void* workspace, size_t workspace_bytes,
+                            sph3d_stream_t stream);
+size_t sph3d_pointwise_gemm_tn_workspace(int R, int Cin, int Cout);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPH3D_H */
