@@ -1,0 +1,259 @@
+#!/usr/bin/env python
+"""bench.py — headline metric of BASELINE.json: point-cloud blocks/s, forward + backward (+ Adam step),
+SPH3D_s3dis-shaped network on 8192-point S3DIS-like blocks, 16 blocks per GPU (weak scaling).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A "step" = graph construction (nnquery, FPS, buildkernel: they depend on the input xyz, so they are part
+of every step) + forward + loss + backward + gradient all-reduce (N > 1) + optimiser update, on one batch
+of synthetic blocks already resident in HBM.  Rank 0 prints ONE JSON line (contract in the task brief),
+with two extra objects:
+  roofline     — the dominant libsph3d kernel of the timed region: algorithmic bytes (SURVEY §8d formulas)
+                 / its mean device time measured with HIP events on the launching stream during the timed steps;
+  cpu_baseline — the same harness step on the CPU oracle (oracle/, OpenMP over all host cores) on a bounded
+                 sample of the same workload; rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from sph3d_gcn_amd import _lib
+from sph3d_gcn_amd import tf_gemm
+from sph3d_gcn_amd.harness import dist as hdist
+from sph3d_gcn_amd.harness import s3dis_net, synth
+
+BLOCKS_PER_GPU = 16
+NUM_POINT = 8192
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def algorithmic_bytes(name, a):
+    """Compulsory HBM bytes of one C-ABI call (every distinct input/output element once, 4 B each; gathered
+    re-reads are NOT counted) — SURVEY §8(d).  `a` = the call's integer arguments in ABI order."""
+    if name == "sph3d_build_sphere_neighbor":
+        B, N, M, K = a[:4]
+        return 4 * B * (3 * N + 3 * M + 2 * M * K + M)
+    if name == "sph3d_spherical_kernel":
+        B, N, M, K = a[:4]
+        return 4 * B * (3 * N + 3 * M + 3 * M * K + M)
+    if name == "sph3d_depthwise_conv3d":
+        B, N, M, F, C, r, K = a[:7]
+        return 4 * (B * N * C + 2 * B * M * K + B * M + F * C * r + B * M * C * r)
+    if name == "sph3d_depthwise_conv3d_grad":
+        B, N, M, F, C, r, K = a[:7]
+        return 4 * (B * N * C + 2 * B * M * K + B * M + F * C * r + B * M * C * r) + 4 * (B * N * C + F * C * r)
+    if name == "sph3d_farthest_point_sample":
+        b, n, m = a[:3]
+        return 4 * b * (3 * n + m)
+    if name in ("sph3d_max_pool3d", "sph3d_avg_pool3d"):
+        B, N, M, C, K = a[:5]
+        return 4 * B * (N * C + M * K + M + M * C + (M * C if name == "sph3d_max_pool3d" else 0))
+    if name in ("sph3d_mean_interpolate", "sph3d_weighted_interpolate"):
+        B, Nf, Mc, C, K = a[:5]
+        return 4 * B * (Mc * C + Nf * K + Nf + Nf * C + (Nf * K if name == "sph3d_weighted_interpolate" else 0))
+    if name in ("sph3d_avg_pool3d_grad", "sph3d_mean_interpolate_grad", "sph3d_weighted_interpolate_grad"):
+        B, N, M, C, K = a[:5]
+        return 4 * B * (N * C + M * K + M + M * C)
+    if name == "sph3d_max_pool3d_grad":
+        B, N, M, C = a[:4]
+        return 4 * B * (N * C + 2 * M * C)
+    if name == "sph3d_pointwise_gemm":
+        R, Cin, Cout = a[:3]
+        return 4 * (R * Cin + Cin * Cout + R * Cout)
+    if name == "sph3d_pointwise_gemm_tn":
+        R, Cin, Cout = a[:3]
+        return 4 * (R * Cin + Cin * Cout + R * Cout)
+    return 0
+
+
+def make_batch(rank, dev):
+    first = 1000 + rank * BLOCKS_PER_GPU
+    xyz, label, inner = synth.s3dis_batch(first, BLOCKS_PER_GPU, NUM_POINT)
+    return (torch.from_numpy(xyz).to(dev), torch.from_numpy(label).to(dev), torch.from_numpy(inner).to(dev))
+
+
+def train_step(model, flat, opt, pts, label, inner):
+    flat.zero()
+    graphs = s3dis_net.build_graphs(pts, model.config)
+    pred, _ = model(pts, is_training=True, graphs=graphs)
+    loss = model.loss(pred, label, inner)
+    loss.backward()
+    flat.all_reduce()
+    opt.step()
+    return loss
+
+
+def cpu_baseline(seconds_target=12.0, sample_blocks=2):
+    """Same harness step on the CPU oracle (kind = "port").  Bounded: `sample_blocks` S3DIS blocks per step,
+    repeated until ~seconds_target of CPU work (at least one step after one warm-up-free cold step)."""
+    import oracle  # noqa: F401  (cpu_baseline leg: the oracle is the thing timed here, by design)
+    from oracle import torch_ops
+    cores = os.cpu_count() or 1
+    xyz, label, inner = synth.s3dis_batch(5000, sample_blocks, NUM_POINT)
+    pts, label, inner = torch.from_numpy(xyz), torch.from_numpy(label), torch.from_numpy(inner)
+    torch.set_num_threads(cores)
+    with torch_ops.patched_util():
+        model = s3dis_net.SPH3DS3DIS(s3dis_net.s3dis_config(NUM_POINT), device=torch.device("cpu"))
+        with torch.no_grad():
+            pass
+        # one cold step creates the variables (not timed), then the optimiser
+        graphs = s3dis_net.build_graphs(pts, model.config)
+        pred, _ = model(pts, is_training=True, graphs=graphs)
+        model.loss(pred, label, inner).backward()
+        flat = hdist.FlatGradAllReduce(model.parameters())
+        opt = torch.optim.Adam([flat.flat_param], lr=1e-3, eps=1e-4)
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            train_step(model, flat, opt, pts, label, inner)
+            steps += 1
+            el = time.perf_counter() - t0
+            if el >= seconds_target or steps >= 20:
+                break
+    return {"value": round(steps * sample_blocks / el, 4), "unit": "blocks/s", "cores": cores, "kind": "port",
+            "sample": "%d step(s) x %d S3DIS-like 8192-pt blocks, full SPH3D_s3dis fwd+bwd+Adam on oracle/ "
+                      "(C, OpenMP) with torch-CPU GEMM/BN, %.1f s" % (steps, sample_blocks, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm", default=os.environ.get("SPH3D_GEMM", tf_gemm.get_backend()))
+    args = ap.parse_args()
+
+    rank, world, local_rank = hdist.init_from_env()
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback in the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    _lib.lib()
+    tf_gemm.set_backend(args.gemm)
+
+    pts, label, inner = make_batch(rank, dev)
+    model = s3dis_net.SPH3DS3DIS(s3dis_net.s3dis_config(NUM_POINT), device=dev)
+    # variables are created by the first forward (TF-style scopes): one untimed pass, then flat buffers + Adam
+    graphs = s3dis_net.build_graphs(pts, model.config)
+    pred, _ = model(pts, is_training=True, graphs=graphs)
+    model.loss(pred, label, inner).backward()
+    flat = hdist.FlatGradAllReduce(model.parameters())
+    flat.broadcast_params(0)
+    opt = torch.optim.Adam([flat.flat_param], lr=1e-3, eps=1e-4)   # train_s3dis.py:224 (epsilon=1e-4)
+    nparams = flat.flat_param.numel()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        train_step(model, flat, opt, pts, label, inner)
+
+    barrier()
+    torch.cuda.synchronize()
+    _lib.timing_start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step(model, flat, opt, pts, label, inner)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    events = _lib.timing_stop()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel device time from the HIP events recorded during the timed steps ----
+    per = {}
+    for name, ints, e0, e1 in events:
+        ms = e0.elapsed_time(e1)
+        key = (name, ints)
+        d = per.setdefault(key, [0.0, 0])
+        d[0] += ms
+        d[1] += 1
+    ranked = sorted(per.items(), key=lambda kv: -kv[1][0])
+    kernels = []
+    for (name, ints), (ms, cnt) in ranked[:8]:
+        ab = algorithmic_bytes(name, ints)
+        avg_ms = ms / cnt
+        kernels.append({"op": name, "dims": list(ints[:7]), "calls_per_step": cnt / args.steps,
+                        "avg_us": round(avg_ms * 1e3, 1), "ms_per_step": round(ms / args.steps, 3),
+                        "alg_GB": round(ab / 1e9, 4), "GBps": round(ab / 1e9 / (avg_ms / 1e3), 1) if avg_ms > 0 else None})
+    roofline = None
+    if ranked:
+        (name, ints), (ms, cnt) = ranked[0]
+        ab = algorithmic_bytes(name, ints)
+        avg_s = ms / cnt / 1e3
+        achieved = ab / 1e9 / avg_s
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("%s%s" % (name, list(ints[:7])))
+            except Exception:
+                traffic = None
+        roofline = {"kernel": name, "dims": list(ints[:7]), "bound": "hbm", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "alg_bytes": ab, "avg_us": round(avg_s * 1e6, 1), "traffic": traffic}
+    # the north-star "conv gather" line: depthwise forward at (B=16, N=M=8192, C=128, r=2, K=64)
+    conv_gather = None
+    for (name, ints), (ms, cnt) in per.items():
+        if name == "sph3d_depthwise_conv3d" and ints[:7] == (BLOCKS_PER_GPU, NUM_POINT, NUM_POINT, 33, 128, 2, 64):
+            ab = algorithmic_bytes(name, ints)
+            avg_s = ms / cnt / 1e3
+            conv_gather = {"avg_us": round(avg_s * 1e6, 1), "achieved": round(ab / 1e9 / avg_s, 1), "unit": "GB/s",
+                           "frac": round(ab / 1e9 / avg_s / HBM_PEAK_GBS, 4), "alg_bytes": ab}
+    sph3d_ms = sum(v[0] for v in per.values()) / args.steps
+
+    if rank == 0:
+        blocks = world * BLOCKS_PER_GPU * args.steps
+        out = {
+            "metric": "point-cloud blocks/sec (fwd+bwd) SPH3D_s3dis 8192-pt",
+            "value": round(blocks / elapsed, 3),
+            "unit": "blocks/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "SPH3D_s3dis seg net (s3dis_config.py plan), S3DIS-like 8192-pt blocks, "
+                                   "%d blocks/GPU, graph build + fwd + bwd + Adam" % BLOCKS_PER_GPU,
+                       "global_batch": world * BLOCKS_PER_GPU, "points_per_block": NUM_POINT,
+                       "parallelism": "dp%d (one cloud shard per GPU, one flat RCCL grad all-reduce)" % world,
+                       "params": nparams, "gemm_backend": tf_gemm.get_backend()},
+            "loss": round(float(loss), 5),
+            "sph3d_kernels_ms_per_step": round(sph3d_ms, 3),
+            "roofline": roofline,
+            "conv_gather": conv_gather,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,168 @@
+"""ctypes binding of libsph3d.so — the C ABI declared in include/sph3d.h.
+
+This is the ONLY compute path of the package.  There is no CPU or eager-PyTorch
+fallback: if the library is missing or a tensor is not on a HIP device the ops
+raise.  (The CPU oracle lives in /oracle and is test infrastructure.)
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsph3d.so")
+
+_c_int = ctypes.c_int
+_c_float = ctypes.c_float
+_c_size_t = ctypes.c_size_t
+_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); one entry per declaration in include/sph3d.h
+_I, _F, _P, _S = _c_int, _c_float, _vp, _c_size_t
+SIGNATURES = {
+    "sph3d_abi_version": (_I, []),
+    "sph3d_last_error": (ctypes.c_char_p, []),
+    "sph3d_build_info": (ctypes.c_char_p, []),
+    "sph3d_build_sphere_neighbor": (_I, [_I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
+    "sph3d_build_cube_neighbor": (_I, [_I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P]),
+    "sph3d_spherical_kernel": (_I, [_I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "sph3d_depthwise_conv3d": (_I, [_I] * 7 + [_P] * 7),
+    "sph3d_depthwise_conv3d_grad_workspace": (_S, [_I] * 7),
+    "sph3d_depthwise_conv3d_grad": (_I, [_I] * 7 + [_P] * 8 + [_P, _S, _P]),
+    "sph3d_max_pool3d": (_I, [_I] * 5 + [_P] * 6),
+    "sph3d_max_pool3d_grad": (_I, [_I] * 4 + [_P] * 4),
+    "sph3d_avg_pool3d": (_I, [_I] * 5 + [_P] * 5),
+    "sph3d_avg_pool3d_grad": (_I, [_I] * 5 + [_P] * 5),
+    "sph3d_mean_interpolate": (_I, [_I] * 5 + [_P] * 5),
+    "sph3d_mean_interpolate_grad": (_I, [_I] * 5 + [_P] * 5),
+    "sph3d_weighted_interpolate": (_I, [_I] * 5 + [_P] * 6),
+    "sph3d_weighted_interpolate_grad": (_I, [_I] * 5 + [_P] * 6),
+    "sph3d_farthest_point_sample_workspace": (_S, [_I] * 3),
+    "sph3d_farthest_point_sample": (_I, [_I] * 3 + [_P, _P, _P, _S, _P]),
+    "sph3d_pointwise_gemm": (_I, [_I] * 3 + [_P, _P, _P, _I, _I, _P, _P]),
+    "sph3d_pointwise_gemm_tn_workspace": (_S, [_I] * 3),
+    "sph3d_pointwise_gemm_tn": (_I, [_I] * 3 + [_P, _P, _P, _P, _S, _P]),
+}
+# test-only hook exported by the library but not part of the reference surface
+_EXTRA = {
+    "sph3d_selftest_math": (_I, [_I, _P, _P, _P, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class Sph3dError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libsph3d.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Sph3dError(
+            "libsph3d.so is not built (%s).  Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C sph3d_gcn_amd/csrc`.  There is no fallback path." % LIB_PATH)
+    l = ctypes.CDLL(LIB_PATH)
+    for table in (SIGNATURES, _EXTRA):
+        for name, (res, args) in table.items():
+            try:
+                fn = getattr(l, name)
+            except AttributeError:
+                if table is SIGNATURES and not name.startswith("sph3d_pointwise_gemm"):
+                    raise Sph3dError("libsph3d.so does not export %s" % name)
+                continue
+            fn.restype = res
+            fn.argtypes = args
+    if l.sph3d_abi_version() != 1:
+        raise Sph3dError("libsph3d.so ABI version mismatch")
+    _lib = _Proxy(l)
+    return _lib
+
+
+# ---- optional per-call HIP-event timing (bench.py's roofline leg) ---------------------------------
+# When enabled, every kernel-launching C-ABI call is bracketed by two events recorded on the stream the
+# kernel is launched on (torch's current stream), so elapsed_time() is that call's device time.
+_timing = None
+
+
+def timing_start():
+    global _timing
+    _timing = []
+
+
+def timing_stop():
+    """-> list of (name, int_args, start_event, end_event); events are resolved by the caller after a sync"""
+    global _timing
+    out, _timing = _timing, None
+    return out
+
+
+_NO_TIME = ("sph3d_abi_version", "sph3d_last_error", "sph3d_build_info", "workspace")
+
+
+class _Proxy:
+    """Attribute access returns the ctypes function, wrapped with event timing while timing is on."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+        self._cache = {}
+
+    def __getattr__(self, name):
+        fn = getattr(self._cdll, name)     # AttributeError if not exported
+        if any(k in name for k in _NO_TIME):
+            return fn
+        w = self._cache.get(name)
+        if w is None:
+            def w(*args, _fn=fn, _name=name):
+                if _timing is None:
+                    return _fn(*args)
+                st = torch.cuda.current_stream()
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                rc = _fn(*args)
+                e1.record(st)
+                _timing.append((_name, tuple(a for a in args if isinstance(a, int)), e0, e1))
+                return rc
+            self._cache[name] = w
+        return w
+
+
+def check(rc):
+    """Map a C-ABI status to the exception the reference's OP_REQUIRES would have raised."""
+    if rc == 0:
+        return
+    msg = lib().sph3d_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError(msg)          # errors::InvalidArgument
+    raise Sph3dError("libsph3d status %d: %s" % (rc, msg))
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise Sph3dError("sph3d ops run on the HIP device only (got a %s tensor); "
+                             "the CPU oracle is test infrastructure, not a fallback" % t.device)
+
+
+def f32(t):
+    """contiguous float32 view/copy on the same device"""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def i32(t):
+    if t.dtype != torch.int32:
+        t = t.int()
+    return t.contiguous()
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)

@@ -1,0 +1,113 @@
+// buildkernel.hip — spherical-kernel bin assignment for gfx950.
+//
+// Replaces build_spherical_kernel (tf_ops/buildkernel/tf_buildkernel_gpu.cu:20-79).
+// One lane per (query, neighbour slot): the op is elementwise over the [B,M,K] neighbour table,
+// so the reference's thread-per-query serial loop over K becomes a fully coalesced sweep of
+// nn_index / nn_dist / filt_index (each 4 B per lane, contiguous across the wave), with the two
+// gathered xyz reads served from L2 (a cloud's xyz is <= 96 KB).
+//
+// Bit-exactness notes (must match oracle_sphere_bin):
+//   * M_PI in the reference is the glibc double macro, so the clamp / shift / divide-by-pi steps run in
+//     double and round to float on assignment; reproduced literally below.
+//   * atan2f is include/sph3d_atan2f.h (shared with the oracle), not ocml.
+//   * built with -ffp-contract=off.
+#include "common.hpp"
+#include "../../include/sph3d_atan2f.h"
+
+namespace sph3d {
+
+#define SPH3D_PI 3.14159265358979323846   // double, == glibc M_PI
+
+__device__ __forceinline__ int sphere_bin(float dx, float dy, float dz, float dist, float radius, int n, int p, int q)
+{
+    const float M_EPSf = 1.01e-3F;                                     // tf_buildkernel_gpu.cu:5-7
+    float dist2D = dx * dx + dy * dy;                                  // :49
+    dist2D = sqrtf(dist2D);                                            // :50
+    if (!(dist > M_EPSf && (double)fabsf(dist - M_EPSf) > 1e-6)) return 0;   // :52-53 self / coincident
+    float theta = sph3d_atan2f(dy, dx);                                // :55
+    float phi = sph3d_atan2f(dz, dist2D);                              // :56
+    theta = (float)((double)theta < SPH3D_PI ? (double)theta : -SPH3D_PI);        // :58
+    theta = (float)((double)theta > -SPH3D_PI ? (double)theta : -SPH3D_PI);       // :59
+    theta = (float)((double)theta + SPH3D_PI);                                    // :60
+    phi = (float)((double)phi < (SPH3D_PI / 2) ? (double)phi : (SPH3D_PI / 2));   // :62
+    phi = (float)((double)phi > (-SPH3D_PI / 2) ? (double)phi : (-SPH3D_PI / 2)); // :63
+    phi = (float)((double)phi + SPH3D_PI / 2);                                    // :64
+    const float alpha = (float)((double)((theta * (float)n) / 2.0f) / SPH3D_PI);  // :66
+    const float beta = (float)((double)(phi * (float)p) / SPH3D_PI);              // :67
+    const float gamma = (dist * (float)q) / (radius + 1e-6F);                     // :68
+    int nID = (int)alpha; nID = nID < n - 1 ? nID : n - 1;                        // :70-72
+    int pID = (int)beta;  pID = pID < p - 1 ? pID : p - 1;
+    int qID = (int)gamma; qID = qID < q - 1 ? qID : q - 1;
+    return qID * p * n + pID * n + nID + 1;                                       // :74
+}
+
+__global__ __launch_bounds__(256) void spherical_kernel_kernel(
+    int B, int N, int M, int K, int n, int p, int q, float radius,
+    const float* __restrict__ database, const float* __restrict__ query,
+    const int* __restrict__ nnIndex, const int* __restrict__ nnCount, const float* __restrict__ nnDist,
+    int* __restrict__ filtIndex)
+{
+    const long long total = (long long)B * M * K;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const long long row = e / K;          // (b, m)
+        const int k = (int)(e - row * K);
+        const int b = (int)(row / M);
+        int out = 0;                          // slots >= nn_count stay 0 (tf_buildkernel.cpp:89)
+        if (k < nnCount[row]) {
+            const int ptID = nnIndex[e];
+            const float* pt = database + ((size_t)b * N + ptID) * 3;
+            const float* qp = query + (size_t)row * 3;
+            const float dx = pt[0] - qp[0];
+            const float dy = pt[1] - qp[1];
+            const float dz = pt[2] - qp[2];
+            out = sphere_bin(dx, dy, dz, nnDist[e], radius, n, p, q);
+        }
+        filtIndex[e] = out;
+    }
+}
+
+// test hook: evaluates the shared scalar math on arrays so tests can compare device vs host bit patterns
+__global__ void selftest_math_kernel(int n, const float* a, const float* b, float* out_atan2, float* out_sqrt,
+                                     float* out_div, int* out_bin)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out_atan2[i] = sph3d_atan2f(a[i], b[i]);
+    out_sqrt[i] = sqrtf(fabsf(a[i]));
+    out_div[i] = a[i] / b[i];
+    out_bin[i] = sphere_bin(a[i], b[i], a[i] * b[i], sqrtf(sqrtf(a[i] * a[i] + b[i] * b[i])), 0.1f, 8, 2, 2);
+}
+
+}  // namespace sph3d
+
+using namespace sph3d;
+
+extern "C" int sph3d_spherical_kernel(int B, int N, int M, int K, int n, int p, int q, float radius,
+                                      const float* database, const float* query,
+                                      const int* nn_index, const int* nn_count, const float* nn_dist,
+                                      int* filt_index, sph3d_stream_t stream)
+{
+    SPH3D_REQUIRE(radius > 0, "Range search requires radius>0, got %g", (double)radius);   // tf_buildkernel.cpp:40
+    SPH3D_REQUIRE(n > 2 && n % 2 == 0, "Need n_>2 and n_%%2==0, got %d", n);               // :43
+    SPH3D_REQUIRE(p > 0 && p % 2 == 0, "Need p_>0 and p_%%2==0, got %d", p);               // :46
+    SPH3D_REQUIRE(q > 0, "Need q_>0, got %d", q);                                          // :49
+    SPH3D_REQUIRE(B >= 0 && N > 0 && M >= 0 && K > 0, "SphericalKernel: bad dims B=%d N=%d M=%d K=%d", B, N, M, K);
+    const long long total = (long long)B * M * K;
+    if (total == 0) return SPH3D_OK;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(spherical_kernel_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                       B, N, M, K, n, p, q, radius, database, query, nn_index, nn_count, nn_dist, filt_index);
+    return check_launch("sph3d_spherical_kernel");
+}
+
+// not part of the reference surface: device-side evaluation of the shared scalar math (tests only)
+extern "C" int sph3d_selftest_math(int n, const float* a, const float* b, float* out_atan2, float* out_sqrt,
+                                   float* out_div, int* out_bin, sph3d_stream_t stream)
+{
+    if (n <= 0) return SPH3D_OK;
+    hipLaunchKernelGGL(selftest_math_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream),
+                       n, a, b, out_atan2, out_sqrt, out_div, out_bin);
+    return check_launch("sph3d_selftest_math");
+}

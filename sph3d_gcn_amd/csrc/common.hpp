@@ -1,0 +1,75 @@
+// common.hpp — shared host/device helpers for libsph3d (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/sph3d.h"
+
+namespace sph3d {
+
+constexpr int kWave = 64;           // CDNA wavefront width
+constexpr int kRefGrid = 32;        // the reference launches every kernel <<<32,1024>>>;
+constexpr int kRefBlock = 1024;     // its thread->work mapping defines the radius-growth chains and FPS tie-break
+
+// ---- host-side status plumbing ------------------------------------------------
+void set_error(const char* fmt, ...);   // stores a thread-local message (api.cpp)
+
+#define SPH3D_REQUIRE(cond, ...)                    \
+    do {                                            \
+        if (!(cond)) {                              \
+            ::sph3d::set_error(__VA_ARGS__);        \
+            return SPH3D_EINVAL;                    \
+        }                                           \
+    } while (0)
+
+static inline int check_launch(const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return SPH3D_ELAUNCH;
+    }
+    return SPH3D_OK;
+}
+
+static inline int check_hip(hipError_t e, const char* what)
+{
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return SPH3D_ELAUNCH;
+    }
+    return SPH3D_OK;
+}
+
+static inline hipStream_t as_stream(sph3d_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- device helpers -----------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ int prefix_popc(unsigned long long mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// make a wave-uniform int visibly scalar to the compiler
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uniformf(float v)
+{
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+// XCD-affine work decode.  Workgroup `bid` runs on XCD (bid % 8) (observed placement, used for
+// L2 locality only, never for correctness).  Clouds are dealt to XCDs round-robin so that all
+// workgroups of one cloud share one L2: returns (cloud, part) for this block or cloud = -1.
+__device__ __forceinline__ void xcd_decode(int bid, int B, int parts, int& cloud, int& part)
+{
+    const int x = bid & 7;
+    const int y = bid >> 3;
+    cloud = x + 8 * (y / parts);
+    part = y % parts;
+    if (cloud >= B) cloud = -1;
+}
+static inline int xcd_grid(int B, int parts) { return 8 * ((B + 7) / 8) * parts; }
+
+}  // namespace sph3d

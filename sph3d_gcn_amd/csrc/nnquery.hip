@@ -1,0 +1,303 @@
+// nnquery.hip — range / cube neighbour search for gfx950.
+//
+// Replaces cal_nn_binidx / cal_nn_binidx_cube (tf_ops/nnquery/tf_nnquery_gpu.cu:15-113).
+//
+// MI355X design (not the reference's thread-per-query serial scan):
+//   * The reference mutates its `radius` parameter inside each thread and never resets it, so
+//     the queries a reference thread (block i%32, thread j%1024) visits form a CHAIN whose
+//     search radius depends on everything before it.  A chain is therefore the unit of
+//     sequential work here: one wavefront owns CPW chains and walks them query by query,
+//     while its 64 lanes scan the database 64 points at a time ("strip").
+//   * Ascending-index, first-K-win slotting inside a strip is a ballot plus a prefix popcount
+//     (v_mbcnt), so no atomics and no sorting.
+//   * The cloud's xyz are staged once per workgroup in LDS as SoA (<= 144 KB of the 160 KB),
+//     16 waves per workgroup, so the O(M*N) scan never touches HBM/L2 again.
+//   * The in-range predicate  sqrtf(d2) < r && |sqrtf(d2)-r| > 1e-6  is monotone in d2, so per
+//     (chain, pass) the wave finds the exact float threshold T(r) with a 64-ary search over float
+//     bit patterns (6 rounds) and the inner loop is sub/mul/add/compare only: no sqrt per pair,
+//     bit-identical decisions.
+//   * -ffp-contract=off: d2 = (dx*dx + dy*dy) + dz*dz must round exactly like the oracle.
+#include "common.hpp"
+
+namespace sph3d {
+
+constexpr int kWavesPerWG = 16;
+constexpr int kMaxChunk = 12288;   // points per LDS chunk (3 * 12288 * 4 B = 144 KB)
+
+// the reference's predicate on the euclidean distance s (tf_nnquery_gpu.cu:49)
+__device__ __forceinline__ bool in_range(float s, float r)
+{
+    return s < r && (double)fabsf(s - r) > 1e-6;
+}
+
+// Wave-cooperative, all 64 lanes active, r wave-uniform.
+// Returns the smallest non-negative float T with !in_range(sqrtf(T), r); then
+// in_range(sqrtf(d2), r) == (d2 < T) for every d2 >= 0 (and false for NaN on both sides).
+__device__ float range_threshold(float r)
+{
+    if (!in_range(0.0f, r)) return 0.0f;
+    const unsigned lane = (unsigned)lane_id();
+    unsigned lo = 0u;             // in_range holds at lo
+    unsigned hi = 0x7f800000u;    // +inf: in_range fails
+    while (hi - lo > 1u) {
+        const unsigned span = hi - lo;
+        const unsigned step = span / 65u + 1u;
+        const unsigned long long c = (unsigned long long)lo + (unsigned long long)step * (lane + 1u);
+        const bool p = (c < hi) && in_range(sqrtf(__uint_as_float((unsigned)c)), r);
+        const int nt = __popcll(__ballot(p));   // p is a prefix of the lanes (monotone predicate)
+        const unsigned long long nhi = (unsigned long long)lo + (unsigned long long)step * (unsigned)(nt + 1);
+        if (nhi < hi) hi = (unsigned)nhi;
+        lo = lo + step * (unsigned)nt;
+    }
+    return __uint_as_float(hi);
+}
+
+// stage `cn` points starting at point c0 of one cloud into SoA LDS arrays
+__device__ __forceinline__ void stage_cloud(const float* __restrict__ dbi, int c0, int cn, int chunkN, float* lds)
+{
+    const float* src = dbi + (size_t)c0 * 3;
+    for (int e = threadIdx.x; e < cn * 3; e += blockDim.x) {
+        const float v = src[e];
+        const int pnt = e / 3;
+        const int comp = e - pnt * 3;
+        lds[comp * chunkN + pnt] = v;
+    }
+}
+
+template <int CPW, bool MULTI>
+__global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
+    int B, int N, int M, int K, float radius0, int chunkN, int groups,
+    const float* __restrict__ database, const float* __restrict__ query,
+    int* __restrict__ nnIndex, int* __restrict__ nnCount, float* __restrict__ nnDist)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const float* lx = lds;
+    const float* ly = lds + chunkN;
+    const float* lz = lds + 2 * chunkN;
+
+    const int nt = M < kRefBlock ? M : kRefBlock;
+    const int bb = (int)blockIdx.x / groups;     // reference block id  (= cloud index mod 32)
+    const int g = (int)blockIdx.x % groups;
+    const int wave = uniform((int)threadIdx.x >> 6);
+    const int lane = lane_id();
+
+    int t[CPW];        // reference thread id of each chain
+    float r[CPW];      // the chain's running radius (carried across queries AND clouds)
+#pragma unroll
+    for (int c = 0; c < CPW; c++) {
+        t[c] = (g * kWavesPerWG + wave) * CPW + c;
+        r[c] = radius0;
+    }
+
+    for (int i = bb; i < B; i += kRefGrid) {
+        const float* dbi = database + (size_t)i * N * 3;
+        const float* qi = query + (size_t)i * M * 3;
+
+        int j[CPW], s[CPW], passes[CPW];
+        bool has[CPW];
+        float qx[CPW], qy[CPW], qz[CPW], thr[CPW];
+#pragma unroll
+        for (int c = 0; c < CPW; c++) {
+            j[c] = t[c];
+            has[c] = (t[c] < nt) && (j[c] < M);
+            s[c] = 0;
+            passes[c] = 0;
+            qx[c] = qy[c] = qz[c] = 0.0f;
+            thr[c] = 0.0f;
+            if (has[c]) {
+                qx[c] = qi[j[c] * 3];
+                qy[c] = qi[j[c] * 3 + 1];
+                qz[c] = qi[j[c] * 3 + 2];
+                thr[c] = range_threshold(r[c]);
+            }
+        }
+
+        if (!MULTI) {
+            __syncthreads();   // previous cloud's scans are finished
+            stage_cloud(dbi, 0, N, chunkN, lds);
+            __syncthreads();
+        }
+
+        while (true) {
+            bool any = false;
+#pragma unroll
+            for (int c = 0; c < CPW; c++) any = any || has[c];
+            if (MULTI) any = __syncthreads_or(any ? 1 : 0) != 0;
+            if (!any) break;
+
+            // ---- one sweep over the database for every active chain of this wave ----
+            for (int c0 = 0; c0 < N; c0 += chunkN) {
+                const int cn = (N - c0) < chunkN ? (N - c0) : chunkN;
+                if (MULTI) {
+                    __syncthreads();
+                    stage_cloud(dbi, c0, cn, chunkN, lds);
+                    __syncthreads();
+                }
+                for (int base = 0; base < cn; base += 64) {
+                    bool open = false;   // some chain still has free slots
+#pragma unroll
+                    for (int c = 0; c < CPW; c++) open = open || (has[c] && s[c] < K);
+                    if (!open) break;
+                    const int k = base + lane;
+                    const bool inb = k < cn;
+                    const int kk = inb ? k : cn - 1;
+                    const float x = lx[kk], y = ly[kk], z = lz[kk];
+#pragma unroll
+                    for (int c = 0; c < CPW; c++) {
+                        if (has[c] && s[c] < K) {   // wave-uniform
+                            const float dx = x - qx[c];
+                            const float dy = y - qy[c];
+                            const float dz = z - qz[c];
+                            const float d2 = (dx * dx + dy * dy) + dz * dz;   // tf_nnquery_gpu.cu:45-46
+                            const bool hit = inb && (d2 < thr[c]);
+                            const unsigned long long mask = __ballot(hit);
+                            if (mask != 0ull) {
+                                const int pos = s[c] + prefix_popc(mask);
+                                if (hit && pos < K) {
+                                    const size_t o = ((size_t)i * M + j[c]) * K + pos;
+                                    nnIndex[o] = c0 + k;
+                                    nnDist[o] = sqrtf(sqrtf(d2));   // :47 then :54 — sqrt of the distance
+                                }
+                                s[c] += __popcll(mask);
+                            }
+                        }
+                    }
+                }
+            }
+
+            // ---- end of pass: grow the radius (tf_nnquery_gpu.cu:59), maybe finish the query ----
+#pragma unroll
+            for (int c = 0; c < CPW; c++) {
+                if (has[c]) {
+                    r[c] = (float)((double)r[c] + 0.05);
+                    passes[c]++;
+                    if (s[c] > 0 || passes[c] >= SPH3D_MAX_GROWTH_PASSES) {
+                        const int cnt = s[c] < K ? s[c] : K;
+                        const size_t row = (size_t)i * M + j[c];
+                        if (lane == 0) nnCount[row] = cnt;
+                        for (int slot = cnt + lane; slot < K; slot += 64) {   // unused slots read 0
+                            nnIndex[row * K + slot] = 0;
+                            nnDist[row * K + slot] = 0.0f;
+                        }
+                        j[c] += kRefBlock;
+                        has[c] = j[c] < M;
+                        s[c] = 0;
+                        passes[c] = 0;
+                        if (has[c]) {
+                            qx[c] = qi[j[c] * 3];
+                            qy[c] = qi[j[c] * 3 + 1];
+                            qz[c] = qi[j[c] * 3 + 2];
+                        }
+                    }
+                    if (has[c]) thr[c] = range_threshold(r[c]);
+                }
+            }
+        }
+    }
+}
+
+// Cube search: queries are independent (no growth loop), one wave per query, database from L2.
+__global__ __launch_bounds__(256) void nnquery_cube_kernel(
+    int B, int N, int M, int G, int K, float length,
+    const float* __restrict__ database, const float* __restrict__ query,
+    int* __restrict__ nnIndex, int* __restrict__ nnCount)
+{
+    const int lane = lane_id();
+    const int wid = uniform((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+    const float half = length / 2;            // tf_nnquery_gpu.cu:96  (float / int)
+    const float cell = length / (float)G;     // :99
+    for (long long qid = wid; qid < (long long)B * M; qid += nwaves) {
+        const int i = (int)(qid / M);
+        const float* dbi = database + (size_t)i * N * 3;
+        const float qx = query[qid * 3], qy = query[qid * 3 + 1], qz = query[qid * 3 + 2];
+        int* row = nnIndex + (size_t)qid * K * 2;
+        int s = 0;
+        for (int base = 0; base < N && s < K; base += 64) {
+            const int k = base + lane;
+            const bool inb = k < N;
+            const int kk = inb ? k : N - 1;
+            const float dx = dbi[kk * 3] - qx;
+            const float dy = dbi[kk * 3 + 1] - qy;
+            const float dz = dbi[kk * 3 + 2] - qz;
+            const bool hit = inb && fabsf(dx) < half && fabsf(dy) < half && fabsf(dz) < half;
+            const unsigned long long mask = __ballot(hit);
+            if (mask != 0ull) {
+                const int pos = s + prefix_popc(mask);
+                if (hit && pos < K) {
+                    const int xId = (int)((dx + half) / cell);
+                    const int yId = (int)((dy + half) / cell);
+                    const int zId = (int)((dz + half) / cell);
+                    row[pos * 2] = k;
+                    row[pos * 2 + 1] = xId * G * G + yId * G + zId;
+                }
+                s += __popcll(mask);
+            }
+        }
+        const int cnt = s < K ? s : K;
+        if (lane == 0) nnCount[qid] = cnt;
+        for (int slot = cnt * 2 + lane; slot < K * 2; slot += 64) row[slot] = 0;
+    }
+}
+
+template <int CPW, bool MULTI>
+static int launch_sphere(int B, int N, int M, int K, float radius, int chunkN,
+                         const float* database, const float* query,
+                         int* nn_index, int* nn_count, float* nn_dist, hipStream_t stream)
+{
+    const int nb = B < kRefGrid ? B : kRefGrid;
+    const int nt = M < kRefBlock ? M : kRefBlock;
+    const int groups = (nt + kWavesPerWG * CPW - 1) / (kWavesPerWG * CPW);
+    const size_t lds = (size_t)3 * chunkN * sizeof(float);
+    auto kern = nnquery_sphere_kernel<CPW, MULTI>;
+    if (lds > 64 * 1024) {
+        int rc = check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                           "nnquery: hipFuncSetAttribute");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(kern, dim3(nb * groups), dim3(kWavesPerWG * 64), lds, stream,
+                       B, N, M, K, radius, chunkN, groups, database, query, nn_index, nn_count, nn_dist);
+    return check_launch("sph3d_build_sphere_neighbor");
+}
+
+}  // namespace sph3d
+
+using namespace sph3d;
+
+extern "C" int sph3d_build_sphere_neighbor(int B, int N, int M, int nn_sample, float radius,
+                                           const float* database, const float* query,
+                                           int* nn_index, int* nn_count, float* nn_dist,
+                                           sph3d_stream_t stream)
+{
+    SPH3D_REQUIRE(radius > 0, "Range search requires radius>0, got %g", (double)radius);          // tf_nnquery.cpp:60
+    SPH3D_REQUIRE(nn_sample > 0, "BuildSphereNeighbor requires nn_sample>0, got %d", nn_sample);  // :63
+    SPH3D_REQUIRE(B >= 0 && N > 0 && M >= 0, "BuildSphereNeighbor: bad dims B=%d N=%d M=%d", B, N, M);
+    if (B == 0 || M == 0) return SPH3D_OK;
+    hipStream_t st = as_stream(stream);
+    const int chunkN = N < kMaxChunk ? N : kMaxChunk;
+    const bool multi = N > chunkN;
+    const long long chains = (long long)(B < kRefGrid ? B : kRefGrid) * (M < kRefBlock ? M : kRefBlock);
+    if (multi) return launch_sphere<1, true>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st);
+    if (chains >= 256LL * kWavesPerWG * 4)
+        return launch_sphere<4, false>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st);
+    if (chains >= 256LL * kWavesPerWG * 2)
+        return launch_sphere<2, false>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st);
+    return launch_sphere<1, false>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st);
+}
+
+extern "C" int sph3d_build_cube_neighbor(int B, int N, int M, int grid_size, int nn_sample, float length,
+                                         const float* database, const float* query,
+                                         int* nn_index, int* nn_count, sph3d_stream_t stream)
+{
+    SPH3D_REQUIRE(length > 0, "Cube search requires length>0, got %g", (double)length);
+    SPH3D_REQUIRE(nn_sample > 0, "BuildCubeNeighbor requires nn_sample>0, got %d", nn_sample);
+    SPH3D_REQUIRE(grid_size > 0, "BuildCubeNeighbor requires grid_size>0, got %d", grid_size);
+    SPH3D_REQUIRE(B >= 0 && N > 0 && M >= 0, "BuildCubeNeighbor: bad dims B=%d N=%d M=%d", B, N, M);
+    if (B == 0 || M == 0) return SPH3D_OK;
+    const long long q = (long long)B * M;
+    long long blocks = (q + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(nnquery_cube_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                       B, N, M, grid_size, nn_sample, length, database, query, nn_index, nn_count);
+    return check_launch("sph3d_build_cube_neighbor");
+}

@@ -1,0 +1,270 @@
+// pool3d.hip — graph max/avg pooling and mean/weighted un-pooling (forward + gradients), gfx950.
+//
+// Replaces max_pool3d_forward/backward, avg_pool3d_forward/backward (tf_ops/pooling/tf_pool3d_gpu.cu:5-90)
+// and mean/weighted_interpolate_forward/backward (tf_ops/unpooling/tf_unpool3d_gpu.cu:5-84).
+//
+// All eight kernels are the same shape of work — "for every output point, walk its neighbour list and
+// combine gathered feature rows" — so they share one skeleton: one wavefront per output point, the
+// neighbour row fetched once (lane k = slot k) and broadcast with v_readlane, lanes spanning channels
+// with float4 (or scalar when C % 4 != 0) coalesced row reads, accumulation in registers, one store.
+// The reference used one thread per (point, channel) with a global read-modify-write per neighbour
+// and a cudaDeviceSynchronize after every launch (tf_pool3d_gpu.cu:97,104,111,118).
+// Un-pooling "mean" is avg-pooling with the roles of the point sets swapped, so it reuses that kernel.
+// Scatter gradients use hardware fp32 atomics (global_atomic_add_f32).
+#include "common.hpp"
+
+namespace sph3d {
+
+constexpr int kPtsPerWG = 16;   // 4 waves x 4 points
+
+enum class Mode { Max, Avg, Weighted };
+
+// V = 4: channels c0 + 4*lane + {0..3} per pass of 256 channels; V = 1: c0 + lane (64 per pass)
+template <Mode MODE, int V>
+__global__ __launch_bounds__(256) void gather_fwd(
+    int B, int Nin, int Mout, int C, int K, int mblocks,
+    const int* __restrict__ nnIndex, const int* __restrict__ nnCount,
+    const float* __restrict__ input, const float* __restrict__ weight,
+    float* __restrict__ output, int* __restrict__ maxIndex)
+{
+    int b, mb;
+    xcd_decode((int)blockIdx.x, B, mblocks, b, mb);
+    if (b < 0) return;
+    const int wave = uniform((int)threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int m_begin = mb * kPtsPerWG;
+    const int m_end = (m_begin + kPtsPerWG) < Mout ? (m_begin + kPtsPerWG) : Mout;
+    const float* inb = input + (size_t)b * Nin * C;
+
+    for (int m = m_begin + wave; m < m_end; m += 4) {
+        const size_t row = (size_t)b * Mout + m;
+        const int cnt = uniform(nnCount[row]);
+        for (int c0 = 0; c0 < C; c0 += 64 * V) {
+            const int c = c0 + lane * V;
+            const bool act = c < C;
+            float acc[V];
+            int arg[V];
+#pragma unroll
+            for (int v = 0; v < V; v++) { acc[v] = 0.f; arg[v] = 0; }
+            const int* __restrict__ irow = nnIndex + row * K;   // wave-uniform address -> scalar loads
+            const float* __restrict__ wrow = weight + row * K;
+            {
+#pragma unroll 4
+                for (int kk = 0; kk < cnt; kk++) {
+                    const int n = irow[kk];
+                    float w = 1.f;
+                    if (MODE == Mode::Weighted) w = wrow[kk];
+                    if (act) {
+                        float x[V];
+                        if (V == 4) {
+                            const float4 t = *reinterpret_cast<const float4*>(&inb[(size_t)n * C + c]);
+                            x[0] = t.x; x[1 % V] = t.y; x[2 % V] = t.z; x[3 % V] = t.w;
+                        } else {
+                            x[0] = inb[(size_t)n * C + c];
+                        }
+#pragma unroll
+                        for (int v = 0; v < V; v++) {
+                            if (MODE == Mode::Max) {
+                                // first neighbour seeds, strict > replaces (tf_pool3d_gpu.cu:17-29)
+                                if (kk == 0 || x[v] > acc[v]) { acc[v] = x[v]; arg[v] = n; }
+                            } else if (MODE == Mode::Avg) {
+                                acc[v] += x[v];
+                            } else {
+                                acc[v] = fmaf(x[v], w, acc[v]);     // tf_unpool3d_gpu.cu:59
+                            }
+                        }
+                    }
+                }
+            }
+            if (act) {
+#pragma unroll
+                for (int v = 0; v < V; v++) {
+                    float o = acc[v];
+                    if (MODE == Mode::Avg) o = cnt > 0 ? o / (float)cnt : 0.f;
+                    output[row * C + c + v] = o;
+                    if (MODE == Mode::Max) maxIndex[row * C + c + v] = arg[v];
+                }
+            }
+        }
+    }
+}
+
+// scatter gradient of avg-pool / mean- and weighted-interpolate:
+//   gradInput[b, idx_k, c] += gradOutput[b, m, c] * (1/cnt  or  w_k)
+template <Mode MODE, int V>
+__global__ __launch_bounds__(256) void scatter_bwd(
+    int B, int Nin, int Mout, int C, int K, int mblocks,
+    const int* __restrict__ nnIndex, const int* __restrict__ nnCount,
+    const float* __restrict__ gradOutput, const float* __restrict__ weight,
+    float* __restrict__ gradInput)
+{
+    int b, mb;
+    xcd_decode((int)blockIdx.x, B, mblocks, b, mb);
+    if (b < 0) return;
+    const int wave = uniform((int)threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int m_begin = mb * kPtsPerWG;
+    const int m_end = (m_begin + kPtsPerWG) < Mout ? (m_begin + kPtsPerWG) : Mout;
+    float* ginb = gradInput + (size_t)b * Nin * C;
+
+    for (int m = m_begin + wave; m < m_end; m += 4) {
+        const size_t row = (size_t)b * Mout + m;
+        const int cnt = uniform(nnCount[row]);
+        if (cnt <= 0) continue;
+        for (int c0 = 0; c0 < C; c0 += 64 * V) {
+            const int c = c0 + lane * V;
+            const bool act = c < C;
+            float go[V];
+#pragma unroll
+            for (int v = 0; v < V; v++) {
+                go[v] = act ? gradOutput[row * C + c + v] : 0.f;
+                if (MODE == Mode::Avg) go[v] = go[v] / (float)cnt;      // tf_pool3d_gpu.cu:86
+            }
+            const int* __restrict__ irow = nnIndex + row * K;   // wave-uniform address -> scalar loads
+            const float* __restrict__ wrow = weight + row * K;
+            {
+#pragma unroll 4
+                for (int kk = 0; kk < cnt; kk++) {
+                    const int n = irow[kk];
+                    float w = 1.f;
+                    if (MODE == Mode::Weighted) w = wrow[kk];
+                    if (act) {
+#pragma unroll
+                        for (int v = 0; v < V; v++)
+                            unsafeAtomicAdd(&ginb[(size_t)n * C + c + v], MODE == Mode::Weighted ? go[v] * w : go[v]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// max-pool gradient: gradInput[b, maxIndex[b,m,c], c] += gradOutput[b,m,c]   (tf_pool3d_gpu.cu:38-50)
+__global__ __launch_bounds__(256) void maxpool_bwd(
+    int B, int N, int M, int C, const int* __restrict__ maxIndex,
+    const float* __restrict__ gradOutput, float* __restrict__ gradInput)
+{
+    const long long total = (long long)B * M * C;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long per_b = (long long)M * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int b = (int)(e / per_b);
+        const int c = (int)(e % C);
+        const int n = maxIndex[e];
+        unsafeAtomicAdd(&gradInput[((size_t)b * N + n) * C + c], gradOutput[e]);
+    }
+}
+
+template <Mode MODE>
+static int launch_fwd(const char* who, int B, int Nin, int Mout, int C, int K,
+                      const int* nn_index, const int* nn_count, const float* input, const float* weight,
+                      float* output, int* max_index, hipStream_t st)
+{
+    SPH3D_REQUIRE(B >= 0 && Nin > 0 && Mout >= 0 && C > 0 && K > 0, "%s: bad dims B=%d N=%d M=%d C=%d K=%d",
+                  who, B, Nin, Mout, C, K);
+    if (B == 0 || Mout == 0) return SPH3D_OK;
+    const int mblocks = (Mout + kPtsPerWG - 1) / kPtsPerWG;
+    const dim3 grid(xcd_grid(B, mblocks));
+    if (C % 4 == 0)
+        hipLaunchKernelGGL((gather_fwd<MODE, 4>), grid, dim3(256), 0, st, B, Nin, Mout, C, K, mblocks,
+                           nn_index, nn_count, input, weight, output, max_index);
+    else
+        hipLaunchKernelGGL((gather_fwd<MODE, 1>), grid, dim3(256), 0, st, B, Nin, Mout, C, K, mblocks,
+                           nn_index, nn_count, input, weight, output, max_index);
+    return check_launch(who);
+}
+
+template <Mode MODE>
+static int launch_bwd(const char* who, int B, int Nin, int Mout, int C, int K,
+                      const int* nn_index, const int* nn_count, const float* grad_output, const float* weight,
+                      float* grad_input, hipStream_t st)
+{
+    SPH3D_REQUIRE(B >= 0 && Nin > 0 && Mout >= 0 && C > 0 && K > 0, "%s: bad dims B=%d N=%d M=%d C=%d K=%d",
+                  who, B, Nin, Mout, C, K);
+    if (B == 0) return SPH3D_OK;
+    int rc = check_hip(hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)B * Nin * C, st), who);
+    if (rc) return rc;
+    if (Mout == 0) return SPH3D_OK;
+    const int mblocks = (Mout + kPtsPerWG - 1) / kPtsPerWG;
+    const dim3 grid(xcd_grid(B, mblocks));
+    if (C % 4 == 0)
+        hipLaunchKernelGGL((scatter_bwd<MODE, 4>), grid, dim3(256), 0, st, B, Nin, Mout, C, K, mblocks,
+                           nn_index, nn_count, grad_output, weight, grad_input);
+    else
+        hipLaunchKernelGGL((scatter_bwd<MODE, 1>), grid, dim3(256), 0, st, B, Nin, Mout, C, K, mblocks,
+                           nn_index, nn_count, grad_output, weight, grad_input);
+    return check_launch(who);
+}
+
+}  // namespace sph3d
+
+using namespace sph3d;
+
+extern "C" int sph3d_max_pool3d(int B, int N, int M, int C, int K, const int* nn_index, const int* nn_count,
+                                const float* input, float* output, int* max_index, sph3d_stream_t stream)
+{
+    return launch_fwd<Mode::Max>("sph3d_max_pool3d", B, N, M, C, K, nn_index, nn_count, input, nullptr, output,
+                                 max_index, as_stream(stream));
+}
+
+extern "C" int sph3d_max_pool3d_grad(int B, int N, int M, int C, const int* max_index, const float* grad_output,
+                                     float* grad_input, sph3d_stream_t stream)
+{
+    SPH3D_REQUIRE(B >= 0 && N > 0 && M >= 0 && C > 0, "MaxPool3dGrad: bad dims B=%d N=%d M=%d C=%d", B, N, M, C);
+    if (B == 0) return SPH3D_OK;
+    hipStream_t st = as_stream(stream);
+    int rc = check_hip(hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)B * N * C, st), "sph3d_max_pool3d_grad");
+    if (rc) return rc;
+    const long long total = (long long)B * M * C;
+    if (total == 0) return SPH3D_OK;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(maxpool_bwd, dim3((unsigned)blocks), dim3(256), 0, st, B, N, M, C, max_index, grad_output, grad_input);
+    return check_launch("sph3d_max_pool3d_grad");
+}
+
+extern "C" int sph3d_avg_pool3d(int B, int N, int M, int C, int K, const int* nn_index, const int* nn_count,
+                                const float* input, float* output, sph3d_stream_t stream)
+{
+    return launch_fwd<Mode::Avg>("sph3d_avg_pool3d", B, N, M, C, K, nn_index, nn_count, input, nullptr, output,
+                                 nullptr, as_stream(stream));
+}
+
+extern "C" int sph3d_avg_pool3d_grad(int B, int N, int M, int C, int K, const int* nn_index, const int* nn_count,
+                                     const float* grad_output, float* grad_input, sph3d_stream_t stream)
+{
+    return launch_bwd<Mode::Avg>("sph3d_avg_pool3d_grad", B, N, M, C, K, nn_index, nn_count, grad_output, nullptr,
+                                 grad_input, as_stream(stream));
+}
+
+// un-pooling: the reference's N is the fine (output) count and M the coarse (input) count
+extern "C" int sph3d_mean_interpolate(int B, int N, int M, int C, int K, const int* nn_index, const int* nn_count,
+                                      const float* input, float* output, sph3d_stream_t stream)
+{
+    return launch_fwd<Mode::Avg>("sph3d_mean_interpolate", B, /*Nin=*/M, /*Mout=*/N, C, K, nn_index, nn_count, input,
+                                 nullptr, output, nullptr, as_stream(stream));
+}
+
+extern "C" int sph3d_mean_interpolate_grad(int B, int N, int M, int C, int K, const int* nn_index,
+                                           const int* nn_count, const float* grad_output, float* grad_input,
+                                           sph3d_stream_t stream)
+{
+    return launch_bwd<Mode::Avg>("sph3d_mean_interpolate_grad", B, M, N, C, K, nn_index, nn_count, grad_output,
+                                 nullptr, grad_input, as_stream(stream));
+}
+
+extern "C" int sph3d_weighted_interpolate(int B, int N, int M, int C, int K, const int* nn_index,
+                                          const int* nn_count, const float* input, const float* weight,
+                                          float* output, sph3d_stream_t stream)
+{
+    return launch_fwd<Mode::Weighted>("sph3d_weighted_interpolate", B, M, N, C, K, nn_index, nn_count, input, weight,
+                                      output, nullptr, as_stream(stream));
+}
+
+extern "C" int sph3d_weighted_interpolate_grad(int B, int N, int M, int C, int K, const int* nn_index,
+                                               const int* nn_count, const float* grad_output, const float* weight,
+                                               float* grad_input, sph3d_stream_t stream)
+{
+    return launch_bwd<Mode::Weighted>("sph3d_weighted_interpolate_grad", B, M, N, C, K, nn_index, nn_count,
+                                      grad_output, weight, grad_input, as_stream(stream));
+}

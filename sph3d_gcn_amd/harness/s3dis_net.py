@@ -1,0 +1,173 @@
+"""SPH3D_s3dis call pattern on s3g_util (torch restatement of models/SPH3D_s3dis.py:11-133).
+
+This is harness code for bench.py / smoke(): it exists so that the headline metric
+(point-cloud blocks/s, forward+backward, SPH3D_s3dis, 8192-point blocks) exercises the ops through
+the same sequence of s3g_util calls, with the same shapes, as the reference's model graph.
+The config mirrors s3dis_seg/s3dis_config.py:3-26.
+"""
+import copy
+import types
+
+import torch
+import torch.nn.functional as F
+
+from .. import sph3gcn_util as s3g_util
+
+
+def s3dis_config(num_input=8192):
+    c = types.SimpleNamespace()
+    c.num_input = num_input
+    c.num_cls = 13
+    c.mlp = 64
+    c.num_sample = [2048, 768, 384, 128]
+    c.radius = [0.1, 0.2, 0.4, 0.8]
+    c.nn_uplimit = [64, 64, 64, 64]
+    c.channels = [[128, 128], [256, 256], [256, 256], [512, 512]]
+    c.multiplier = [[2, 2], [2, 2], [2, 2], [2, 2]]
+    c.weight_decay = None
+    c.kernel = [8, 2, 2]
+    c.binSize = 8 * 2 * 2 + 1
+    c.normalize = True
+    c.pool_method = 'max'
+    c.unpool_method = 'mean'
+    c.sample = 'FPS'
+    c.with_bn = True
+    c.with_bias = False
+    return c
+
+
+def small_config(num_input=1024):
+    """Reduced plan for smoke / CPU-oracle plumbing (BASELINE config #1 flavour)."""
+    c = s3dis_config(num_input)
+    c.num_sample = [256, 64]
+    c.radius = [0.1, 0.2]
+    c.nn_uplimit = [32, 32]
+    c.channels = [[32, 32], [64, 64]]
+    c.multiplier = [[2, 2], [2, 1]]
+    c.mlp = 16
+    return c
+
+
+def normalize_xyz(points):
+    """models/SPH3D_s3dis.py:11-19"""
+    min_xyz = points.min(dim=1, keepdim=True)[0]
+    max_xyz = points.max(dim=1, keepdim=True)[0]
+    center = (max_xyz + min_xyz) / 2
+    xy = points[:, :, 0:2] - center[:, :, 0:2]
+    z = points[:, :, 2:]
+    return torch.cat((xy, z), dim=2)
+
+
+def _separable_conv3d_block(net, list_channels, bin_size, nn_index, nn_count, filt_idx, name,
+                            depth_multiplier=None, weight_decay=None, reuse=None, with_bn=True,
+                            with_bias=True, is_training=None):
+    """models/SPH3D_s3dis.py:22-32"""
+    for l, num_out_channels in enumerate(list_channels):
+        scope = name + '_' + str(l + 1)
+        net = s3g_util.separable_conv3d(net, num_out_channels, bin_size, depth_multiplier[l], scope, nn_index,
+                                        nn_count, filt_idx, weight_decay=weight_decay, with_bn=with_bn,
+                                        with_bias=with_bias, reuse=reuse, is_training=is_training)
+    return net
+
+
+def build_graphs(points, config):
+    """All graph-construction ops of one forward (they depend on xyz only): returns the
+    encoder and decoder graph lists.  Separated so the bench can time / overlap it explicitly."""
+    xyz = points[:, :, 0:3]
+    enc = []
+    xyz_layers = [xyz]
+    for l in range(len(config.radius)):
+        intra_idx, intra_cnt, intra_dst, indices = s3g_util.build_graph(
+            xyz, config.radius[l], config.nn_uplimit[l], config.num_sample[l], sample_method=config.sample)
+        filt_idx = s3g_util.spherical_kernel(xyz, xyz, intra_idx, intra_cnt, intra_dst, config.radius[l],
+                                             kernel=config.kernel)
+        g = dict(intra_idx=intra_idx, intra_cnt=intra_cnt, filt_idx=filt_idx)
+        if config.num_sample[l] > 1:
+            xyz = s3g_util.gather_nd(xyz, indices)
+            xyz_layers.append(xyz)
+            g["inter_idx"] = s3g_util.gather_nd(intra_idx, indices)
+            g["inter_cnt"] = s3g_util.gather_nd(intra_cnt, indices)
+        enc.append(g)
+    radius = list(reversed(config.radius))
+    nn_uplimit = list(reversed(config.nn_uplimit))
+    xyz_rev = list(reversed(xyz_layers))
+    dec = []
+    for l in range(len(radius)):
+        xyz = xyz_rev[l]
+        xyz_unpool = xyz_rev[l + 1]
+        intra_idx, intra_cnt, intra_dst, inter_idx, inter_cnt, inter_dst = s3g_util.build_graph_deconv(
+            xyz, xyz_unpool, radius[l], nn_uplimit[l])
+        filt_idx = s3g_util.spherical_kernel(xyz, xyz, intra_idx, intra_cnt, intra_dst, radius[l],
+                                             kernel=config.kernel)
+        dec.append(dict(intra_idx=intra_idx, intra_cnt=intra_cnt, filt_idx=filt_idx, inter_idx=inter_idx,
+                        inter_cnt=inter_cnt, inter_dst=inter_dst))
+    return enc, dec
+
+
+def get_model(points, is_training, config=None, graphs=None):
+    """models/SPH3D_s3dis.py:35-113 (config lists are not reversed in place here)."""
+    end_points = {}
+    xyz = points[:, :, 0:3]
+    norm_xyz = normalize_xyz(xyz) if config.normalize else xyz
+    reuse = None
+    net = torch.cat((norm_xyz, points[:, :, 6:]), dim=2)
+    net = s3g_util.pointwise_conv3d(net, config.mlp, 'mlp1', weight_decay=config.weight_decay,
+                                    with_bn=config.with_bn, with_bias=config.with_bias, reuse=reuse,
+                                    is_training=is_training)
+    if graphs is None:
+        graphs = build_graphs(points, config)
+    enc, dec = graphs
+    encoder = []
+    for l in range(len(config.radius)):
+        g = enc[l]
+        net = _separable_conv3d_block(net, config.channels[l], config.binSize, g["intra_idx"], g["intra_cnt"],
+                                      g["filt_idx"], 'conv' + str(l + 1), config.multiplier[l], reuse=reuse,
+                                      weight_decay=config.weight_decay, with_bn=config.with_bn,
+                                      with_bias=config.with_bias, is_training=is_training)
+        encoder.append(net)
+        if config.num_sample[l] > 1:
+            net = s3g_util.pool3d(net, g["inter_idx"], g["inter_cnt"], method=config.pool_method,
+                                  scope='pool' + str(l + 1))
+    channels = list(reversed(config.channels))
+    multiplier = list(reversed(config.multiplier))
+    encoder.reverse()
+    for l in range(len(channels)):
+        g = dec[l]
+        net = _separable_conv3d_block(net, channels[l], config.binSize, g["intra_idx"], g["intra_cnt"],
+                                      g["filt_idx"], 'deconv' + str(l + 1), multiplier[l], reuse=reuse,
+                                      weight_decay=config.weight_decay, with_bn=config.with_bn,
+                                      with_bias=config.with_bias, is_training=is_training)
+        net = s3g_util.unpool3d(net, g["inter_idx"], g["inter_cnt"], g["inter_dst"], method=config.unpool_method,
+                                scope='unpool' + str(l + 1))
+        net = torch.cat((net, encoder[l]), dim=2)
+    end_points['feats'] = net
+    net = s3g_util.pointwise_conv3d(net, config.num_cls, scope='logits', with_bn=False,
+                                    with_bias=config.with_bias, activation_fn=None, is_training=is_training)
+    return net, end_points
+
+
+def get_loss(pred, label, end_points, inner_label):
+    """models/SPH3D_s3dis.py:116-133: sum over the batch of the mean cross-entropy over inner points."""
+    B, N, C = pred.shape
+    loss = F.cross_entropy(pred.reshape(-1, C), label.reshape(-1), reduction='none').reshape(B, N)
+    mask = (inner_label > 0).to(loss.dtype)
+    cnt = mask.sum(dim=1)
+    per_block = (loss * mask).sum(dim=1) / cnt.clamp(min=1.0)
+    per_block = torch.where(cnt > 0, per_block, torch.zeros_like(per_block))
+    return per_block.sum()
+
+
+class SPH3DS3DIS(torch.nn.Module):
+    """Holds the VariableStore so parameters register with the optimiser; forward = get_model."""
+
+    def __init__(self, config=None, device=None, seed=7):
+        super().__init__()
+        self.config = copy.deepcopy(config) if config is not None else s3dis_config()
+        self.store = s3g_util.VariableStore(device=device, seed=seed)
+
+    def forward(self, points, is_training=True, graphs=None):
+        with s3g_util.variable_store(self.store):
+            return get_model(points, is_training, self.config, graphs=graphs)
+
+    def loss(self, pred, label, inner_label):
+        return get_loss(pred, label, None, inner_label)

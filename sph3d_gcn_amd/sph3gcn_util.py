@@ -1,0 +1,324 @@
+"""Op-composition glue with the public signatures of the reference's utils/sph3gcn_util.py.
+
+Every function keeps the reference's name, positional order, keyword names and defaults
+(utils/sph3gcn_util.py:20,28,52,88,166,225,276,300,328) so that a model graph written against
+``s3g_util`` calls it unchanged; the bodies are re-hosted on PyTorch-ROCm and the custom ops run
+libsph3d's HIP kernels.  TF1-isms are mapped as follows:
+
+  * ``scope`` / ``tf.get_variable``  -> a VariableStore (an nn.Module holding a ParameterDict):
+    the first call under a scope creates the variables, later calls reuse them.  The active
+    store is set with ``with variable_store(store):`` (a default global store exists, like
+    TF's default graph).  ``reuse`` is accepted and ignored.
+  * ``is_training``                   -> Python bool (None = True).
+  * ``tf.add_to_collection('losses', ...)`` / regularisation losses -> ``store.collect_losses()``.
+"""
+import contextlib
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import tf_conv3d, tf_pool3d, tf_unpool3d
+from .tf_nnquery import build_sphere_neighbor, build_cube_neighbor
+from .tf_sample import farthest_point_sample, inverse_density_sample, random_sample
+from .tf_buildkernel import spherical_kernel
+from . import tf_gemm
+
+neighbor_fn = build_sphere_neighbor  # default nn search method
+
+elu = F.elu
+
+
+# --------------------------------------------------------------------------------------
+# variable scopes
+# --------------------------------------------------------------------------------------
+class VariableStore(torch.nn.Module):
+    """Named variables created on first use (the role of tf.get_variable + variable_scope)."""
+
+    def __init__(self, device=None, seed=None):
+        super().__init__()
+        self.params = torch.nn.ParameterDict()
+        self._device = device
+        self._gen = None
+        if seed is not None:
+            self._gen = torch.Generator(device="cpu")
+            self._gen.manual_seed(seed)
+        self._decay = []       # (name, coefficient): coefficient * l2_loss(var)   ('losses' collection)
+        self._reg = []         # names under tf.GraphKeys.REGULARIZATION_LOSSES (BN beta/gamma, scale 1.0)
+
+    def _key(self, name):
+        return name.replace(".", "_")
+
+    def has(self, name):
+        return self._key(name) in self.params
+
+    def get_variable(self, name, shape, init_fn, trainable=True):
+        key = self._key(name)
+        if key in self.params:
+            return self.params[key]
+        t = torch.empty(*shape, dtype=torch.float32)
+        init_fn(t, self._gen)
+        if self._device is not None:
+            t = t.to(self._device)
+        p = torch.nn.Parameter(t, requires_grad=trainable)
+        self.params[key] = p
+        return p
+
+    def get_buffer(self, name, shape, value):
+        key = self._key(name)
+        if not hasattr(self, "_buf_" + key):
+            t = torch.full(shape, float(value), dtype=torch.float32)
+            if self._device is not None:
+                t = t.to(self._device)
+            self.register_buffer("_buf_" + key, t)
+        return getattr(self, "_buf_" + key)
+
+    def collect_losses(self):
+        """Sum of the 'losses' collection entries created by weight_decay (utils/sph3gcn_util.py:82-84)."""
+        total = None
+        for name, coef in self._decay:
+            term = 0.5 * self.params[self._key(name)].pow(2).sum() * coef
+            total = term if total is None else total + term
+        return total
+
+    def regularization_loss(self):
+        """tf.losses.get_regularization_loss(): sum of l2_loss over BN beta/gamma (:330-331)."""
+        total = None
+        for name in self._reg:
+            term = 0.5 * self.params[self._key(name)].pow(2).sum()
+            total = term if total is None else total + term
+        return total
+
+
+_default_store = VariableStore()
+_active = [_default_store]
+
+
+def get_variable_store():
+    return _active[-1]
+
+
+@contextlib.contextmanager
+def variable_store(store):
+    _active.append(store)
+    try:
+        yield store
+    finally:
+        _active.pop()
+
+
+def _xavier_uniform(t, gen):
+    # tf.contrib.layers.xavier_initializer(): uniform, fan_in = prod(shape[:-2])*shape[-2], fan_out = ...*shape[-1]
+    shape = t.shape
+    receptive = 1
+    for s in shape[:-2]:
+        receptive *= s
+    fan_in = shape[-2] * receptive if len(shape) > 1 else shape[0]
+    fan_out = shape[-1] * receptive
+    limit = math.sqrt(6.0 / (fan_in + fan_out))
+    with torch.no_grad():
+        t.uniform_(-limit, limit, generator=gen)
+
+
+def _truncated_normal(stddev):
+    def init(t, gen):
+        with torch.no_grad():
+            torch.nn.init.trunc_normal_(t, mean=0.0, std=stddev, a=-2 * stddev, b=2 * stddev, generator=gen)
+    return init
+
+
+def _constant(value):
+    def init(t, gen):
+        with torch.no_grad():
+            t.fill_(value)
+    return init
+
+
+def _variable_with_weight_decay(name, shape, stddev, with_decay, use_xavier=True):
+    """utils/sph3gcn_util.py:61-85"""
+    store = get_variable_store()
+    new = not store.has(name)
+    var = store.get_variable(name, shape, _xavier_uniform if use_xavier else _truncated_normal(stddev))
+    if new and with_decay is not None:
+        store._decay.append((name, with_decay))
+    return var
+
+
+# --------------------------------------------------------------------------------------
+# graph builders (utils/sph3gcn_util.py:20-58)
+# --------------------------------------------------------------------------------------
+def build_global_graph(xyz, query, radius):
+    nn_uplimit = xyz.shape[1]
+    nn_idx, nn_cnt, nn_dst = neighbor_fn(xyz, query, radius=radius, nnsample=nn_uplimit)
+    return nn_idx, nn_cnt, nn_dst
+
+
+def build_graph(xyz, radius, nn_uplimit, num_sample, sample_method=None):
+    intra_idx, intra_cnt, intra_dst = neighbor_fn(xyz, xyz, radius=radius, nnsample=nn_uplimit)
+
+    if num_sample is not None:
+        if sample_method == 'random':
+            sample_index = random_sample(num_sample, xyz)
+        elif sample_method == 'FPS':
+            sample_index = farthest_point_sample(num_sample, xyz)
+        elif sample_method == 'IDS':
+            prob = torch.sum(intra_dst, dim=-1) / intra_cnt.float()
+            sample_index = inverse_density_sample(num_sample, prob)
+        else:
+            raise ValueError('Unknown sampling method.')
+
+        batch_size = xyz.shape[0]
+        batch_indices = torch.arange(batch_size, dtype=torch.int32, device=xyz.device).view(-1, 1, 1)
+        batch_indices = batch_indices.expand(batch_size, num_sample, 1)
+        indices = torch.cat([batch_indices, sample_index.unsqueeze(2).to(torch.int32)], dim=2)
+    else:
+        indices = None
+
+    return intra_idx, intra_cnt, intra_dst, indices
+
+
+def build_graph_deconv(xyz, xyz_unpool, radius, nn_uplimit):
+    intra_idx, intra_cnt, intra_dst = neighbor_fn(xyz, xyz, radius=radius, nnsample=nn_uplimit)
+    inter_idx, inter_cnt, inter_dst = neighbor_fn(xyz, xyz_unpool, radius=radius, nnsample=nn_uplimit)
+    return intra_idx, intra_cnt, intra_dst, inter_idx, inter_cnt, inter_dst
+
+
+def gather_nd(params, indices):
+    """tf.gather_nd for the [B, S, 2] (batch, point) index pairs build_graph returns
+    (used by the model graphs at models/SPH3D_s3dis.py:68-72)."""
+    b = indices[..., 0].long()
+    p = indices[..., 1].long()
+    return params[b, p]
+
+
+# --------------------------------------------------------------------------------------
+# layers (utils/sph3gcn_util.py:88-273)
+# --------------------------------------------------------------------------------------
+def _finish(outputs, num_out_channels, scope, activation_fn, with_bn, with_bias, reuse, is_training, fused_bias=None):
+    if with_bias and fused_bias is None:
+        biases = get_variable_store().get_variable(scope + '/biases', [num_out_channels], _constant(0.0))
+        outputs = outputs + biases
+    if activation_fn is not None:
+        outputs = activation_fn(outputs)
+    if with_bn:
+        outputs = batch_normalization(outputs, is_training, name=scope + '/bn', reuse=reuse)
+    return outputs
+
+
+def separable_conv3d(inputs,
+                     num_out_channels,
+                     kernel_size,
+                     depth_multiplier,
+                     scope,
+                     nn_index,
+                     nn_count,
+                     filt_index,
+                     use_xavier=True,
+                     stddev=1e-3,
+                     weight_decay=None,
+                     activation_fn=elu,
+                     with_bn=False,
+                     with_bias=False,
+                     reuse=None,
+                     is_training=None):
+    """ 3D separable convolution with non-linear operation (utils/sph3gcn_util.py:88-163):
+    depthwise spherical conv -> pointwise matmul -> (bias) -> activation -> (batch norm). """
+    num_in_channels = inputs.shape[-1]
+    depthwise_kernel = _variable_with_weight_decay(scope + '/depthwise_weights',
+                                                   shape=[kernel_size, num_in_channels, depth_multiplier],
+                                                   use_xavier=use_xavier, stddev=stddev,
+                                                   with_decay=weight_decay)
+    outputs = tf_conv3d.depthwise_conv3d(inputs, depthwise_kernel, nn_index, nn_count, filt_index)
+
+    batch_size = outputs.shape[0]
+    num_in_channels = outputs.shape[-1]
+    kernel = _variable_with_weight_decay(scope + '/weights', shape=[num_in_channels, num_out_channels],
+                                         use_xavier=use_xavier, stddev=stddev, with_decay=weight_decay)
+    # pointwise convolution as one GEMM over all points
+    outputs = outputs.reshape(-1, num_in_channels)
+    outputs = tf_gemm.matmul(outputs, kernel)
+    outputs = outputs.reshape(batch_size, -1, num_out_channels)
+    return _finish(outputs, num_out_channels, scope, activation_fn, with_bn, with_bias, reuse, is_training)
+
+
+def pointwise_conv3d(inputs,
+                     num_out_channels,
+                     scope,
+                     use_xavier=True,
+                     stddev=1e-3,
+                     weight_decay=None,
+                     activation_fn=elu,
+                     with_bn=False,
+                     with_bias=False,
+                     reuse=None,
+                     is_training=None):
+    """ pointwise convolution with non-linear operation (utils/sph3gcn_util.py:166-222). """
+    batch_size = inputs.shape[0]
+    num_in_channels = inputs.shape[-1]
+    kernel = _variable_with_weight_decay(scope + '/weights', shape=[num_in_channels, num_out_channels],
+                                         use_xavier=use_xavier, stddev=stddev, with_decay=weight_decay)
+    outputs = tf_gemm.matmul(inputs.reshape(-1, num_in_channels), kernel)
+    outputs = outputs.reshape(batch_size, -1, num_out_channels)
+    return _finish(outputs, num_out_channels, scope, activation_fn, with_bn, with_bias, reuse, is_training)
+
+
+def fully_connected(inputs,
+                    num_out_channels,
+                    scope,
+                    use_xavier=True,
+                    stddev=1e-3,
+                    weight_decay=None,
+                    activation_fn=elu,
+                    with_bn=False,
+                    with_bias=False,
+                    reuse=None,
+                    is_training=None):
+    """ Fully connected layer with non-linear operation (utils/sph3gcn_util.py:225-273). """
+    num_in_channels = inputs.shape[-1]
+    kernel = _variable_with_weight_decay(scope + '/weights', shape=[num_in_channels, num_out_channels],
+                                         use_xavier=use_xavier, stddev=stddev, with_decay=weight_decay)
+    outputs = tf_gemm.matmul(inputs, kernel)
+    return _finish(outputs, num_out_channels, scope, activation_fn, with_bn, with_bias, reuse, is_training)
+
+
+def pool3d(inputs, nn_index, nn_count, scope, method):
+    """ 3D pooling (utils/sph3gcn_util.py:276-297). """
+    if method == 'max':
+        outputs, max_index = tf_pool3d.max_pool3d(inputs, nn_index, nn_count)
+    elif method == 'avg':
+        outputs = tf_pool3d.avg_pool3d(inputs, nn_index, nn_count)
+    else:
+        raise ValueError("Unknow pooling method %s." % method)
+    return outputs
+
+
+def unpool3d(inputs, nn_index, nn_count, nn_dist, scope, method):
+    """ 3D unpooling (utils/sph3gcn_util.py:300-325). """
+    if method == 'mean':
+        outputs = tf_unpool3d.mean_interpolate(inputs, nn_index, nn_count)
+    elif method == 'weighted':
+        sum_nn_dist = torch.sum(nn_dist, dim=-1, keepdim=True)
+        epsilon = 1e-7
+        weight = (nn_dist + epsilon) / (sum_nn_dist + epsilon)
+        outputs = tf_unpool3d.weighted_interpolate(inputs, weight, nn_index, nn_count)
+    else:
+        raise ValueError("Unknow unpooling method %s." % method)
+    return outputs
+
+
+def batch_normalization(data, is_training, name, reuse=None):
+    """tf.layers.batch_normalization(momentum=0.99, epsilon=1e-3 [TF default], axis=-1) with the
+    l2 regularisers on beta/gamma (utils/sph3gcn_util.py:328-332).  Statistics over all but the last axis."""
+    store = get_variable_store()
+    C = data.shape[-1]
+    new = not store.has(name + '/gamma')
+    gamma = store.get_variable(name + '/gamma', [C], _constant(1.0))
+    beta = store.get_variable(name + '/beta', [C], _constant(0.0))
+    if new:
+        store._reg.extend([name + '/gamma', name + '/beta'])
+    moving_mean = store.get_buffer(name + '/moving_mean', (C,), 0.0)
+    moving_var = store.get_buffer(name + '/moving_variance', (C,), 1.0)
+    training = True if is_training is None else bool(is_training)
+    flat = data.reshape(-1, C)
+    out = F.batch_norm(flat, moving_mean, moving_var, gamma, beta, training=training, momentum=1.0 - 0.99, eps=1e-3)
+    return out.reshape(data.shape)

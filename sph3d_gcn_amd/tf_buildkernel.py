@@ -1,0 +1,55 @@
+"""Spherical-kernel bin assignment — mirrors tf_ops/buildkernel/tf_buildkernel.py:10-34.
+
+PyTorch custom op ``sph3d::spherical_kernel`` (no gradient, :34).
+"""
+import torch
+
+from . import _lib
+
+
+@torch.library.custom_op("sph3d::spherical_kernel", mutates_args=())
+def _spherical_kernel(database: torch.Tensor, query: torch.Tensor, nn_index: torch.Tensor,
+                      nn_count: torch.Tensor, nn_dist: torch.Tensor, radius: float,
+                      n_azim: int, p_elev: int, q_radi: int) -> torch.Tensor:
+    _lib.require_device(database, query, nn_index, nn_count, nn_dist)
+    # SphericalKernelGpuOp::Compute checks (tf_buildkernel.cpp:66-68)
+    if database.dim() != 3 or database.shape[2] != 3:
+        raise ValueError("Shape of database points requires to be (batch, npoint, 3)")
+    if query.dim() != 3 or query.shape[2] != 3:
+        raise ValueError("Shape of query points requires to be (batch, mpoint, 3)")
+    if nn_index.dim() != 3:
+        raise ValueError("Shape of nn_index requires to be of rank 3")
+    database, query = _lib.f32(database), _lib.f32(query)
+    nn_index, nn_count, nn_dist = _lib.i32(nn_index), _lib.i32(nn_count), _lib.f32(nn_dist)
+    B, N, _ = database.shape
+    M = query.shape[1]
+    K = nn_index.shape[2]
+    filt_index = torch.empty((B, M, K), dtype=torch.int32, device=database.device)
+    _lib.check(_lib.lib().sph3d_spherical_kernel(
+        B, N, M, K, n_azim, p_elev, q_radi, radius, _lib.ptr(database), _lib.ptr(query),
+        _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(nn_dist), _lib.ptr(filt_index), _lib.stream_ptr()))
+    return filt_index
+
+
+@_spherical_kernel.register_fake
+def _(database, query, nn_index, nn_count, nn_dist, radius, n_azim, p_elev, q_radi):
+    return torch.empty_like(nn_index, dtype=torch.int32)
+
+
+def spherical_kernel(database, query, nn_index, nn_count, nn_dist, radius, kernel=[8, 2, 3]):
+    '''
+    Input:
+        database: (batch, npoint, 3+) float32 array, database points (x,y,z,...)
+        query:    (batch, mpoint, 3+) float32 array, query points (x,y,z,...)
+        nn_index: (batch, mpoint, nnsample) int32 array, neighbor indices
+        nn_count: (batch, mpoint) int32 array, number of neighbors
+        nn_dist: (batch, mpoint, nnsample) float32, sqrt distance array
+        radius:  float32, range search radius
+        kernel:   list of 3 int32, spherical kernel size
+    Output:
+        filt_index: (batch, mpoint, nnsample) int32 array, filter bin indices
+    '''
+    n, p, q = kernel
+    database = database[:, :, 0:3]
+    query = query[:, :, 0:3]
+    return _spherical_kernel(database, query, nn_index, nn_count, nn_dist, float(radius), int(n), int(p), int(q))

@@ -1,0 +1,107 @@
+"""Depthwise spherical convolution — mirrors tf_ops/convolution/tf_conv3d.py:10-32.
+
+PyTorch custom ops ``sph3d::depthwise_conv3d`` and ``sph3d::depthwise_conv3d_grad``; the
+gradient wiring is the reference's @RegisterGradient("DepthwiseConv3d") (:23-32):
+[grad_input, grad_filter, None, None, None].
+"""
+from typing import Tuple
+
+import torch
+
+from . import _lib
+
+
+def _check_conv(input, filter, nn_index, nn_count, bin_index):
+    # DepthwiseConv3dGpuOp::Compute checks (tf_conv3d.cpp:66-72)
+    if input.dim() != 3:
+        raise ValueError("rank of input should be 3")
+    if filter.dim() != 3:
+        raise ValueError("rank of filter should be 3")
+    if filter.shape[1] != input.shape[2]:
+        raise ValueError("Input Channel Size error!")
+    if nn_index.dim() != 3 or bin_index.dim() != 3:
+        raise ValueError("rank of nn_index should be 3")
+    if nn_count.dim() != 2:
+        raise ValueError("rank of nn_count should be 2")
+
+
+@torch.library.custom_op("sph3d::depthwise_conv3d", mutates_args=())
+def _depthwise_conv3d(input: torch.Tensor, filter: torch.Tensor, nn_index: torch.Tensor,
+                      nn_count: torch.Tensor, bin_index: torch.Tensor) -> torch.Tensor:
+    _lib.require_device(input, filter, nn_index, nn_count, bin_index)
+    _check_conv(input, filter, nn_index, nn_count, bin_index)
+    input, filter = _lib.f32(input), _lib.f32(filter)
+    nn_index, nn_count, bin_index = _lib.i32(nn_index), _lib.i32(nn_count), _lib.i32(bin_index)
+    B, N, C = input.shape
+    F, _, r = filter.shape
+    M, K = nn_index.shape[1], nn_index.shape[2]
+    output = torch.empty((B, M, C * r), dtype=torch.float32, device=input.device)
+    _lib.check(_lib.lib().sph3d_depthwise_conv3d(
+        B, N, M, F, C, r, K, _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(bin_index),
+        _lib.ptr(input), _lib.ptr(filter), _lib.ptr(output), _lib.stream_ptr()))
+    return output
+
+
+@_depthwise_conv3d.register_fake
+def _(input, filter, nn_index, nn_count, bin_index):
+    return input.new_empty((input.shape[0], nn_index.shape[1], input.shape[2] * filter.shape[2]))
+
+
+@torch.library.custom_op("sph3d::depthwise_conv3d_grad", mutates_args=())
+def _depthwise_conv3d_grad(input: torch.Tensor, filter: torch.Tensor, grad_output: torch.Tensor,
+                           nn_index: torch.Tensor, nn_count: torch.Tensor,
+                           bin_index: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    _lib.require_device(input, filter, grad_output, nn_index, nn_count, bin_index)
+    _check_conv(input, filter, nn_index, nn_count, bin_index)
+    input, filter, grad_output = _lib.f32(input), _lib.f32(filter), _lib.f32(grad_output)
+    nn_index, nn_count, bin_index = _lib.i32(nn_index), _lib.i32(nn_count), _lib.i32(bin_index)
+    B, N, C = input.shape
+    F, _, r = filter.shape
+    M, K = nn_index.shape[1], nn_index.shape[2]
+    grad_input = torch.empty_like(input)
+    grad_filter = torch.empty_like(filter)
+    l = _lib.lib()
+    wsb = l.sph3d_depthwise_conv3d_grad_workspace(B, N, M, F, C, r, K)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=input.device) if wsb else None
+    _lib.check(l.sph3d_depthwise_conv3d_grad(
+        B, N, M, F, C, r, K, _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(bin_index),
+        _lib.ptr(input), _lib.ptr(filter), _lib.ptr(grad_output), _lib.ptr(grad_input), _lib.ptr(grad_filter),
+        _lib.ptr(ws), wsb, _lib.stream_ptr()))
+    return grad_input, grad_filter
+
+
+@_depthwise_conv3d_grad.register_fake
+def _(input, filter, grad_output, nn_index, nn_count, bin_index):
+    return torch.empty_like(input), torch.empty_like(filter)
+
+
+def _conv_setup(ctx, inputs, output):
+    input, filter, nn_index, nn_count, bin_index = inputs
+    ctx.save_for_backward(input, filter, nn_index, nn_count, bin_index)
+
+
+def _conv_backward(ctx, grad_output):
+    input, filter, nn_index, nn_count, bin_index = ctx.saved_tensors
+    grad_input, grad_filter = _depthwise_conv3d_grad(input, filter, grad_output, nn_index, nn_count, bin_index)
+    return grad_input, grad_filter, None, None, None
+
+
+_depthwise_conv3d.register_autograd(_conv_backward, setup_context=_conv_setup)
+
+
+def depthwise_conv3d(input, filter, nn_index, nn_count, bin_index):
+    '''
+    Input:
+        input:   (batch, npoint, in_channels) float32 array, input point features
+        filter: (binsize, in_channels, channel_multiplier) float32 array, convolution filter
+        nn_index: (batch, mpoint, nnsample) int32 array, neighbor indices
+        nn_count: (batch, mpoint) int32 array, number of neighbors
+        bin_index: (batch, mpoint, nnsample), filtet bins' indices
+    Output:
+        output: (batch, mpoint, out_channels) float32 array, output point features
+    '''
+    return _depthwise_conv3d(input, filter, nn_index, nn_count, bin_index)
+
+
+def depthwise_conv3d_grad(input, filter, grad_output, nn_index, nn_count, bin_index):
+    return _depthwise_conv3d_grad(input, filter, grad_output, nn_index, nn_count, bin_index)

@@ -1,0 +1,94 @@
+"""Pointwise 1x1 feature GEMM — the ``tf.matmul`` inside separable_conv3d / pointwise_conv3d /
+fully_connected (utils/sph3gcn_util.py:146-150, 204-206, 260; cuBLAS SGEMM in the reference).
+
+``matmul(x, w)`` computes x[R,Cin] @ w[Cin,Cout] in exact fp32.  Backends:
+  * "hip"  — libsph3d's hand-written fp32-MFMA kernel (sph3d_pointwise_gemm*), custom op
+             ``sph3d::pointwise_gemm`` with its two backward products;
+  * "blas" — torch.matmul (rocBLAS / hipBLASLt), the library yardstick.
+Select with set_backend() or the SPH3D_GEMM environment variable.
+"""
+import os
+
+import torch
+
+from . import _lib
+
+_backend = os.environ.get("SPH3D_GEMM", "blas")
+
+
+def set_backend(name):
+    global _backend
+    if name not in ("hip", "blas"):
+        raise ValueError("unknown GEMM backend %r" % (name,))
+    _backend = name
+
+
+def get_backend():
+    return _backend
+
+
+def _have_hip_gemm():
+    return hasattr(_lib.lib(), "sph3d_pointwise_gemm")
+
+
+@torch.library.custom_op("sph3d::pointwise_gemm", mutates_args=())
+def _pointwise_gemm(x: torch.Tensor, w: torch.Tensor, trans_w: bool) -> torch.Tensor:
+    """y[R,Cout] = x[R,Cin] @ w[Cin,Cout]   (trans_w: w is stored [Cout,Cin])"""
+    _lib.require_device(x, w)
+    x, w = _lib.f32(x), _lib.f32(w)
+    R, Cin = x.shape
+    Cout = w.shape[0] if trans_w else w.shape[1]
+    y = torch.empty((R, Cout), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().sph3d_pointwise_gemm(R, Cin, Cout, _lib.ptr(x), _lib.ptr(w), None, 0, int(trans_w),
+                                               _lib.ptr(y), _lib.stream_ptr()))
+    return y
+
+
+@_pointwise_gemm.register_fake
+def _(x, w, trans_w):
+    return x.new_empty((x.shape[0], w.shape[0] if trans_w else w.shape[1]))
+
+
+@torch.library.custom_op("sph3d::pointwise_gemm_tn", mutates_args=())
+def _pointwise_gemm_tn(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """dw[Cin,Cout] = x[R,Cin]^T @ dy[R,Cout]"""
+    _lib.require_device(x, dy)
+    x, dy = _lib.f32(x), _lib.f32(dy)
+    R, Cin = x.shape
+    Cout = dy.shape[1]
+    dw = torch.empty((Cin, Cout), dtype=torch.float32, device=x.device)
+    l = _lib.lib()
+    wsb = l.sph3d_pointwise_gemm_tn_workspace(R, Cin, Cout)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device) if wsb else None
+    _lib.check(l.sph3d_pointwise_gemm_tn(R, Cin, Cout, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(ws), wsb,
+                                         _lib.stream_ptr()))
+    return dw
+
+
+@_pointwise_gemm_tn.register_fake
+def _(x, dy):
+    return x.new_empty((x.shape[1], dy.shape[1]))
+
+
+def _gemm_setup(ctx, inputs, output):
+    x, w, trans_w = inputs
+    ctx.save_for_backward(x, w)
+    ctx.trans_w = trans_w
+
+
+def _gemm_backward(ctx, dy):
+    x, w = ctx.saved_tensors
+    if ctx.trans_w:
+        raise RuntimeError("gradient of the transposed-weight form is not needed by the path")
+    dx = _pointwise_gemm(dy, w, True) if ctx.needs_input_grad[0] else None
+    dw = _pointwise_gemm_tn(x, dy) if ctx.needs_input_grad[1] else None
+    return dx, dw, None
+
+
+_pointwise_gemm.register_autograd(_gemm_backward, setup_context=_gemm_setup)
+
+
+def matmul(x, w):
+    if _backend == "hip":
+        return _pointwise_gemm(x, w, False)
+    return torch.matmul(x, w)

@@ -1,0 +1,99 @@
+"""Neighbour search ops — same names and arguments as the reference's
+tf_ops/nnquery/tf_nnquery.py:9-60, running libsph3d's HIP kernels.
+
+Registered as PyTorch custom ops ``sph3d::build_sphere_neighbor`` /
+``sph3d::build_cube_neighbor`` (no gradient, like ops.NoGradient at :33,:60).
+"""
+from typing import Tuple
+
+import torch
+
+from . import _lib
+
+
+@torch.library.custom_op("sph3d::build_sphere_neighbor", mutates_args=())
+def _build_sphere_neighbor(database: torch.Tensor, query: torch.Tensor, radius: float,
+                           nn_sample: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    _lib.require_device(database, query)
+    # shape checks of BuildSphereNeighborGpuOp::Compute (tf_nnquery.cpp:76-77)
+    if database.dim() != 3 or database.shape[2] != 3:
+        raise ValueError("Shape of database points requires to be (batch, npoint, 3)")
+    if query.dim() != 3 or query.shape[2] != 3:
+        raise ValueError("Shape of query points requires to be (batch, mpoint, 3)")
+    database, query = _lib.f32(database), _lib.f32(query)
+    B, N, _ = database.shape
+    M = query.shape[1]
+    nn_index = torch.empty((B, M, nn_sample), dtype=torch.int32, device=database.device)
+    nn_count = torch.empty((B, M), dtype=torch.int32, device=database.device)
+    nn_dist = torch.empty((B, M, nn_sample), dtype=torch.float32, device=database.device)
+    _lib.check(_lib.lib().sph3d_build_sphere_neighbor(
+        B, N, M, nn_sample, radius, _lib.ptr(database), _lib.ptr(query),
+        _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(nn_dist), _lib.stream_ptr()))
+    return nn_index, nn_count, nn_dist
+
+
+@_build_sphere_neighbor.register_fake
+def _(database, query, radius, nn_sample):
+    B, M = query.shape[0], query.shape[1]
+    return (database.new_empty((B, M, nn_sample), dtype=torch.int32),
+            database.new_empty((B, M), dtype=torch.int32),
+            database.new_empty((B, M, nn_sample), dtype=torch.float32))
+
+
+@torch.library.custom_op("sph3d::build_cube_neighbor", mutates_args=())
+def _build_cube_neighbor(database: torch.Tensor, query: torch.Tensor, length: float, nn_sample: int,
+                         grid_size: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    _lib.require_device(database, query)
+    if database.dim() != 3 or database.shape[2] != 3:
+        raise ValueError("Shape of database points requires to be (batch, npoint, 3)")
+    if query.dim() != 3 or query.shape[2] != 3:
+        raise ValueError("Shape of query points requires to be (batch, mpoint, 3)")
+    database, query = _lib.f32(database), _lib.f32(query)
+    B, N, _ = database.shape
+    M = query.shape[1]
+    nn_index = torch.empty((B, M, nn_sample, 2), dtype=torch.int32, device=database.device)
+    nn_count = torch.empty((B, M), dtype=torch.int32, device=database.device)
+    _lib.check(_lib.lib().sph3d_build_cube_neighbor(
+        B, N, M, grid_size, nn_sample, length, _lib.ptr(database), _lib.ptr(query),
+        _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.stream_ptr()))
+    return nn_index, nn_count
+
+
+@_build_cube_neighbor.register_fake
+def _(database, query, length, nn_sample, grid_size):
+    B, M = query.shape[0], query.shape[1]
+    return (database.new_empty((B, M, nn_sample, 2), dtype=torch.int32),
+            database.new_empty((B, M), dtype=torch.int32))
+
+
+def build_sphere_neighbor(database, query, radius=0.1, dilation_rate=None, nnsample=100):
+    '''
+    Input:
+        database: (batch, npoint, 3+x) float32 array, database points
+        query:    (batch, mpoint, 3) float32 array, query points
+        radius:   float32, range search radius
+        dilation_rate: float32, dilation rate of range search
+        nnsample: int32, maximum number of neighbors to be sampled
+    Output:
+        nn_index: (batch, mpoint, nnsample) int32 array, neighbor indices
+        nn_count: (batch, mpoint) int32 array, number of neighbors
+        nn_dist: (batch, mpoint, nnsample) float32, sqrt distance array
+    '''
+    database = database[:, :, 0:3]
+    query = query[:, :, 0:3]
+    if dilation_rate is not None:
+        radius = dilation_rate * radius
+    return _build_sphere_neighbor(database, query, float(radius), int(nnsample))
+
+
+def build_cube_neighbor(database, query, length=0.1, dilation_rate=None, nnsample=100, gridsize=3):
+    '''
+    Output:
+        nn_index: (batch, mpoint, nnsample, 2) int32 array, neighbor and filter bin indices
+        nn_count: (batch, mpoint) int32 array, number of neighbors
+    '''
+    database = database[:, :, 0:3]
+    query = query[:, :, 0:3]
+    if dilation_rate is not None:
+        length = dilation_rate * length
+    return _build_cube_neighbor(database, query, float(length), int(nnsample), int(gridsize))

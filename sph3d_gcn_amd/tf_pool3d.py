@@ -1,0 +1,133 @@
+"""Graph pooling — mirrors tf_ops/pooling/tf_pool3d.py:9-28.
+
+Custom ops ``sph3d::max_pool3d`` (+ ``max_pool3d_grad``) and ``sph3d::avg_pool3d``
+(+ ``avg_pool3d_grad``); gradients wired as the reference's RegisterGradient blocks.
+"""
+from typing import Tuple
+
+import torch
+
+from . import _lib
+
+
+def _check_pool(input, nn_index, nn_count):
+    if input.dim() != 3:
+        raise ValueError("rank of input should be 3")
+    if nn_index.dim() != 3:
+        raise ValueError("rank of nn_index should be 3")
+    if nn_count.dim() != 2:
+        raise ValueError("rank of nn_count should be 2")
+
+
+@torch.library.custom_op("sph3d::max_pool3d", mutates_args=())
+def _max_pool3d(input: torch.Tensor, nn_index: torch.Tensor, nn_count: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    _lib.require_device(input, nn_index, nn_count)
+    _check_pool(input, nn_index, nn_count)
+    input, nn_index, nn_count = _lib.f32(input), _lib.i32(nn_index), _lib.i32(nn_count)
+    B, N, C = input.shape
+    M, K = nn_index.shape[1], nn_index.shape[2]
+    output = torch.empty((B, M, C), dtype=torch.float32, device=input.device)
+    max_index = torch.empty((B, M, C), dtype=torch.int32, device=input.device)
+    _lib.check(_lib.lib().sph3d_max_pool3d(B, N, M, C, K, _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(input),
+                                           _lib.ptr(output), _lib.ptr(max_index), _lib.stream_ptr()))
+    return output, max_index
+
+
+@_max_pool3d.register_fake
+def _(input, nn_index, nn_count):
+    shape = (input.shape[0], nn_index.shape[1], input.shape[2])
+    return input.new_empty(shape), input.new_empty(shape, dtype=torch.int32)
+
+
+@torch.library.custom_op("sph3d::max_pool3d_grad", mutates_args=())
+def _max_pool3d_grad(input: torch.Tensor, grad_output: torch.Tensor, max_index: torch.Tensor) -> torch.Tensor:
+    _lib.require_device(input, grad_output, max_index)
+    grad_output, max_index = _lib.f32(grad_output), _lib.i32(max_index)
+    B, N, C = input.shape
+    M = grad_output.shape[1]
+    grad_input = torch.empty((B, N, C), dtype=torch.float32, device=input.device)
+    _lib.check(_lib.lib().sph3d_max_pool3d_grad(B, N, M, C, _lib.ptr(max_index), _lib.ptr(grad_output),
+                                                _lib.ptr(grad_input), _lib.stream_ptr()))
+    return grad_input
+
+
+@_max_pool3d_grad.register_fake
+def _(input, grad_output, max_index):
+    return torch.empty_like(input)
+
+
+def _max_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], output[1])
+    ctx.mark_non_differentiable(output[1])
+
+
+def _max_backward(ctx, grad_output, grad_index):
+    input, max_index = ctx.saved_tensors
+    return _max_pool3d_grad(input, grad_output, max_index), None, None
+
+
+_max_pool3d.register_autograd(_max_backward, setup_context=_max_setup)
+
+
+@torch.library.custom_op("sph3d::avg_pool3d", mutates_args=())
+def _avg_pool3d(input: torch.Tensor, nn_index: torch.Tensor, nn_count: torch.Tensor) -> torch.Tensor:
+    _lib.require_device(input, nn_index, nn_count)
+    _check_pool(input, nn_index, nn_count)
+    input, nn_index, nn_count = _lib.f32(input), _lib.i32(nn_index), _lib.i32(nn_count)
+    B, N, C = input.shape
+    M, K = nn_index.shape[1], nn_index.shape[2]
+    output = torch.empty((B, M, C), dtype=torch.float32, device=input.device)
+    _lib.check(_lib.lib().sph3d_avg_pool3d(B, N, M, C, K, _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(input),
+                                           _lib.ptr(output), _lib.stream_ptr()))
+    return output
+
+
+@_avg_pool3d.register_fake
+def _(input, nn_index, nn_count):
+    return input.new_empty((input.shape[0], nn_index.shape[1], input.shape[2]))
+
+
+@torch.library.custom_op("sph3d::avg_pool3d_grad", mutates_args=())
+def _avg_pool3d_grad(input: torch.Tensor, grad_output: torch.Tensor, nn_index: torch.Tensor,
+                     nn_count: torch.Tensor) -> torch.Tensor:
+    _lib.require_device(input, grad_output, nn_index, nn_count)
+    grad_output, nn_index, nn_count = _lib.f32(grad_output), _lib.i32(nn_index), _lib.i32(nn_count)
+    B, N, C = input.shape
+    M, K = nn_index.shape[1], nn_index.shape[2]
+    grad_input = torch.empty((B, N, C), dtype=torch.float32, device=input.device)
+    _lib.check(_lib.lib().sph3d_avg_pool3d_grad(B, N, M, C, K, _lib.ptr(nn_index), _lib.ptr(nn_count),
+                                                _lib.ptr(grad_output), _lib.ptr(grad_input), _lib.stream_ptr()))
+    return grad_input
+
+
+@_avg_pool3d_grad.register_fake
+def _(input, grad_output, nn_index, nn_count):
+    return torch.empty_like(input)
+
+
+def _avg_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs)
+
+
+def _avg_backward(ctx, grad_output):
+    input, nn_index, nn_count = ctx.saved_tensors
+    return _avg_pool3d_grad(input, grad_output, nn_index, nn_count), None, None
+
+
+_avg_pool3d.register_autograd(_avg_backward, setup_context=_avg_setup)
+
+
+def max_pool3d(input, nn_index, nn_count):
+    return _max_pool3d(input, nn_index, nn_count)
+
+
+def max_pool3d_grad(input, grad_output, max_index):
+    return _max_pool3d_grad(input, grad_output, max_index)
+
+
+def avg_pool3d(input, nn_index, nn_count):
+    return _avg_pool3d(input, nn_index, nn_count)
+
+
+def avg_pool3d_grad(input, grad_output, nn_index, nn_count):
+    return _avg_pool3d_grad(input, grad_output, nn_index, nn_count)

@@ -1,0 +1,58 @@
+"""Point sampling — mirrors tf_ops/sampling/tf_sample.py:15-49.
+
+``farthest_point_sample`` is the HIP kernel (custom op ``sph3d::farthest_point_sample``,
+no gradient :24).  ``inverse_density_sample`` and ``random_sample`` were stock-TF one-liners in
+the reference (:27-49) and are stock-torch one-liners here (RNG-dependent: parity is statistical).
+"""
+import torch
+
+from . import _lib
+
+
+@torch.library.custom_op("sph3d::farthest_point_sample", mutates_args=())
+def _farthest_point_sample(database: torch.Tensor, npoint: int) -> torch.Tensor:
+    _lib.require_device(database)
+    if npoint <= 0:
+        raise ValueError("FarthestPointSample expects positive npoint")                     # tf_sample.cpp:35
+    if database.dim() != 3 or database.shape[2] != 3:
+        raise ValueError("FarthestPointSample expects (batch_size,num_points,3) inp shape")  # :40
+    database = _lib.f32(database)
+    b, n, _ = database.shape
+    out = torch.empty((b, npoint), dtype=torch.int32, device=database.device)
+    l = _lib.lib()
+    wsb = l.sph3d_farthest_point_sample_workspace(b, n, npoint)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=database.device) if wsb else None
+    _lib.check(l.sph3d_farthest_point_sample(b, n, npoint, _lib.ptr(database), _lib.ptr(out), _lib.ptr(ws), wsb,
+                                             _lib.stream_ptr()))
+    return out
+
+
+@_farthest_point_sample.register_fake
+def _(database, npoint):
+    return database.new_empty((database.shape[0], npoint), dtype=torch.int32)
+
+
+def farthest_point_sample(neursize, database):
+    '''
+    input:
+        neursize: int32, the number of neurons/points to be sampled
+        database: (batch, npoint, 3) float32 array, database points
+    returns:
+        neuron_index: (batch_size, neursize) int32 array, index of sampled neurons in the database
+    '''
+    return _farthest_point_sample(database, int(neursize))
+
+
+def inverse_density_sample(neursize, probability):
+    '''Gumbel-max top-k over log(probability) (tf_sample.py:27-41).'''
+    logits = torch.log(probability)
+    u = torch.rand_like(logits)
+    z = -torch.log(-torch.log(u))
+    _, neuron_index = torch.topk(logits + z, int(neursize), dim=-1)
+    return neuron_index.int()
+
+
+def random_sample(neursize, database):
+    '''uniform sampling with replacement (tf_sample.py:44-49)'''
+    batch_size, num_points = database.shape[0], database.shape[1]
+    return torch.randint(0, num_points, (batch_size, int(neursize)), dtype=torch.int32, device=database.device)

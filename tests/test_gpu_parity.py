@@ -1,0 +1,326 @@
+"""Parity of the HIP kernels (through the C ABI / Python ops) with the CPU oracle and, when the
+prebuilt oracle/_ref library travelled with the snapshot, with the reference's own kernels.
+
+Bars: bit-exact for neighbour indices, counts, bin ids, FPS indices, arg-max ids (and nn_dist, whose
+arithmetic is IEEE sqrt only); 1e-5 (abs+rel) for convolution / pooling activations and gradients.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import ref_gpu
+from sph3d_gcn_amd import tf_nnquery, tf_buildkernel, tf_conv3d, tf_pool3d, tf_unpool3d, tf_sample, _lib
+from sph3d_gcn_amd.harness import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _n(t):
+    return t.detach().cpu().numpy()
+
+
+def _clouds(kind, B, N, seed=0):
+    if kind == "uniform":
+        return synth.uniform_cloud(seed, B, N, 1.0)
+    if kind == "s3dis":
+        return synth.s3dis_batch(seed, B, N)[0]
+    if kind == "modelnet":
+        return synth.modelnet_batch(seed, B, N)
+    raise ValueError(kind)
+
+
+# (kind, B, N, M (None = intra), radius, K)
+NN_CASES = [
+    ("uniform", 1, 16, None, 0.3, 4),          # tiny
+    ("uniform", 2, 100, 37, 0.2, 8),           # ragged sizes, inter graph
+    ("uniform", 33, 1100, None, 0.08, 8),      # both i += 32 and j += 1024 radius carries
+    ("s3dis", 2, 2048, None, 0.1, 64),         # on-grid data, K = 64
+    ("modelnet", 3, 1024, None, 0.1, 64),
+    ("uniform", 4, 1500, 3000, 0.05, 16),      # decoder-like: db != query, isolated queries need growth passes
+    ("uniform", 1, 13000, 200, 0.05, 32),      # N > one LDS chunk (multi-chunk path)
+    ("uniform", 2, 500, 40, 0.01, 70),         # K > 64, many growth passes
+]
+
+
+@pytest.mark.parametrize("case", NN_CASES, ids=lambda c: "%s-B%d-N%d-M%s-r%g-K%d" % c)
+def test_sphere_neighbor_and_kernel_bitexact(dev, case):
+    kind, B, N, M, radius, K = case
+    db = _clouds(kind, B, N, seed=5)
+    q = db if M is None else _clouds("uniform", B, M, seed=9) * db.max()
+    idx_o, cnt_o, dst_o = oracle.build_sphere_neighbor(db, q, radius, None, K)
+    idx, cnt, dst = tf_nnquery.build_sphere_neighbor(_t(db, dev), _t(q, dev), radius, None, K)
+    np.testing.assert_array_equal(_n(cnt), cnt_o)
+    np.testing.assert_array_equal(_n(idx), idx_o)
+    np.testing.assert_array_equal(_n(dst).view(np.int32), dst_o.view(np.int32))   # bit pattern
+    for kernel in ([8, 2, 2], [8, 2, 3], [4, 2, 1]):
+        f_o = oracle.spherical_kernel(db, q, idx_o, cnt_o, dst_o, radius, kernel)
+        f = tf_buildkernel.spherical_kernel(_t(db, dev), _t(q, dev), idx, cnt, dst, radius, kernel)
+        np.testing.assert_array_equal(_n(f), f_o)
+    if ref_gpu.available():
+        ridx, rcnt, rdst = ref_gpu.build_sphere_neighbor(_t(db, dev), _t(q, dev), radius, None, K)
+        np.testing.assert_array_equal(_n(rcnt), cnt_o)
+        np.testing.assert_array_equal(_n(ridx), idx_o)
+        np.testing.assert_array_equal(_n(rdst).view(np.int32), dst_o.view(np.int32))
+        rf = _n(ref_gpu.spherical_kernel(_t(db, dev), _t(q, dev), ridx, rcnt, rdst, radius, [8, 2, 2]))
+        f_o = oracle.spherical_kernel(db, q, idx_o, cnt_o, dst_o, radius, [8, 2, 2])
+        # the reference build uses ocml's atan2f, ours the shared correctly-rounded one: a last-bit
+        # difference can move a neighbour that sits on a bin boundary.  Bound and report.
+        mism = int((rf != f_o).sum())
+        assert mism <= max(2, int(2e-5 * f_o.size)), "filt_index mismatches vs reference build: %d" % mism
+
+
+@pytest.mark.parametrize("B,N,M,K,L,G", [(2, 300, 100, 8, 0.3, 3), (1, 1000, 1000, 20, 0.1, 4), (3, 77, 5, 70, 0.9, 2)])
+def test_cube_neighbor_bitexact(dev, B, N, M, K, L, G):
+    db = _clouds("uniform", B, N, seed=2)
+    q = _clouds("uniform", B, M, seed=3)
+    idx_o, cnt_o = oracle.build_cube_neighbor(db, q, L, None, K, G)
+    idx, cnt = tf_nnquery.build_cube_neighbor(_t(db, dev), _t(q, dev), L, None, K, G)
+    np.testing.assert_array_equal(_n(cnt), cnt_o)
+    np.testing.assert_array_equal(_n(idx), idx_o)
+    if ref_gpu.available():
+        ridx, rcnt = ref_gpu.build_cube_neighbor(_t(db, dev), _t(q, dev), L, None, K, G)
+        np.testing.assert_array_equal(_n(rcnt), cnt_o)
+        np.testing.assert_array_equal(_n(ridx), idx_o)
+
+
+FPS_CASES = [("uniform", 2, 3, 3), ("uniform", 3, 100, 40), ("uniform", 2, 1024, 256), ("s3dis", 2, 2048, 768),
+             ("uniform", 2, 1100, 300), ("modelnet", 2, 10000, 500), ("s3dis", 1, 8192, 2048),
+             ("uniform", 1, 30000, 64)]
+
+
+@pytest.mark.parametrize("case", FPS_CASES, ids=lambda c: "%s-B%d-N%d-m%d" % c)
+def test_fps_bitexact(dev, case):
+    kind, B, N, m = case
+    pts = _clouds(kind, B, N, seed=21)
+    want = oracle.farthest_point_sample(m, pts)
+    got = _n(tf_sample.farthest_point_sample(m, _t(pts, dev)))
+    np.testing.assert_array_equal(got, want)
+    if ref_gpu.available():
+        np.testing.assert_array_equal(_n(ref_gpu.farthest_point_sample(m, _t(pts, dev))), want)
+
+
+def test_fps_tie_break_gpu(dev):
+    rng = np.random.RandomState(0)
+    pts = (rng.rand(1, 2048, 3).astype(np.float32) - 0.5) * 0.15
+    pts[0, 0] = 0
+    pts[0, 1030] = (1, 0, 0)
+    pts[0, 7] = (0, 1, 0)
+    assert _n(tf_sample.farthest_point_sample(3, _t(pts, dev)))[0].tolist() == [0, 1030, 7]
+    # grid data: many exact ties
+    g = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(9), indexing="ij"), -1).reshape(1, -1, 3)
+    g = (g * 0.03).astype(np.float32)
+    want = oracle.farthest_point_sample(200, g)
+    np.testing.assert_array_equal(_n(tf_sample.farthest_point_sample(200, _t(g, dev))), want)
+
+
+def _graph(kind, B, N, M, K, radius, seed):
+    db = _clouds(kind, B, N, seed=seed)
+    q = db if M is None else db[:, :M].copy()
+    idx, cnt, dst = oracle.build_sphere_neighbor(db, q, radius, None, K)
+    filt = oracle.spherical_kernel(db, q, idx, cnt, dst, radius, [8, 2, 2])
+    return db, q, idx, cnt, dst, filt
+
+
+# (B, N, M, C, r, K)
+CONV_CASES = [(2, 200, 100, 8, 2, 16), (1, 64, 64, 3, 1, 8), (2, 300, 300, 35, 2, 32), (2, 256, 256, 67, 1, 64),
+              (2, 500, 500, 64, 2, 64), (1, 300, 150, 128, 2, 64), (1, 128, 128, 1024, 2, 64), (2, 200, 200, 131, 1, 16),
+              (1, 100, 100, 64, 1, 70), (2, 128, 128, 6, 4, 16)]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "B%d-N%d-M%d-C%d-r%d-K%d" % c)
+def test_depthwise_conv_forward_backward(dev, case):
+    B, N, M, C, r, K = case
+    rng = np.random.RandomState(C * 7 + r)
+    db, q, idx, cnt, dst, filt = _graph("uniform", B, N, M if M != N else None, K, 0.25, seed=C)
+    x = rng.randn(B, N, C).astype(np.float32)
+    w = rng.randn(33, C, r).astype(np.float32)
+    go = rng.randn(B, idx.shape[1], C * r).astype(np.float32)
+    out_o = oracle.depthwise_conv3d(x, w, idx, cnt, filt)
+    gi_o, gf_o = oracle.depthwise_conv3d_grad(x, w, go, idx, cnt, filt)
+    xt = _t(x, dev).requires_grad_(True)
+    wt = _t(w, dev).requires_grad_(True)
+    out = tf_conv3d.depthwise_conv3d(xt, wt, _t(idx, dev), _t(cnt, dev), _t(filt, dev))
+    np.testing.assert_allclose(_n(out), out_o, **TOL)
+    out.backward(_t(go, dev))
+    scale_i = max(1.0, float(np.abs(gi_o).max()))
+    scale_f = max(1.0, float(np.abs(gf_o).max()))
+    np.testing.assert_allclose(_n(xt.grad) / scale_i, gi_o / scale_i, **TOL)
+    np.testing.assert_allclose(_n(wt.grad) / scale_f, gf_o / scale_f, **TOL)
+    if ref_gpu.available():
+        rout = ref_gpu.depthwise_conv3d(_t(x, dev), _t(w, dev), _t(idx, dev), _t(cnt, dev), _t(filt, dev))
+        np.testing.assert_allclose(_n(out), _n(rout), **TOL)
+        rgi, rgf = ref_gpu.depthwise_conv3d_grad(_t(x, dev), _t(w, dev), _t(go, dev), _t(idx, dev), _t(cnt, dev),
+                                                 _t(filt, dev))
+        np.testing.assert_allclose(_n(xt.grad) / scale_i, _n(rgi) / scale_i, **TOL)
+        np.testing.assert_allclose(_n(wt.grad) / scale_f, _n(rgf) / scale_f, **TOL)
+
+
+POOL_CASES = [(2, 200, 100, 8, 16), (1, 64, 20, 3, 8), (2, 300, 120, 67, 32), (2, 500, 200, 128, 64),
+              (1, 300, 100, 512, 64), (1, 90, 30, 5, 70)]
+
+
+@pytest.mark.parametrize("case", POOL_CASES, ids=lambda c: "B%d-N%d-M%d-C%d-K%d" % c)
+def test_pooling(dev, case):
+    B, N, M, C, K = case
+    rng = np.random.RandomState(C)
+    db, q, idx, cnt, dst, filt = _graph("uniform", B, N, M, K, 0.25, seed=C + 1)
+    x = rng.randn(B, N, C).astype(np.float32)
+    x[:, ::3] = np.round(x[:, ::3])           # exact ties for the arg-max rule
+    go = rng.randn(B, M, C).astype(np.float32)
+    out_o, mi_o = oracle.max_pool3d(x, idx, cnt)
+    xt = _t(x, dev).requires_grad_(True)
+    out, mi = tf_pool3d.max_pool3d(xt, _t(idx, dev), _t(cnt, dev))
+    np.testing.assert_array_equal(_n(out), out_o)        # pure selection: exact
+    np.testing.assert_array_equal(_n(mi), mi_o)
+    out.backward(_t(go, dev))
+    np.testing.assert_allclose(_n(xt.grad), oracle.max_pool3d_grad(x, go, mi_o), **TOL)
+    xt2 = _t(x, dev).requires_grad_(True)
+    avg = tf_pool3d.avg_pool3d(xt2, _t(idx, dev), _t(cnt, dev))
+    np.testing.assert_allclose(_n(avg), oracle.avg_pool3d(x, idx, cnt), **TOL)
+    avg.backward(_t(go, dev))
+    np.testing.assert_allclose(_n(xt2.grad), oracle.avg_pool3d_grad(x, go, idx, cnt), **TOL)
+    if ref_gpu.available():
+        rout, rmi = ref_gpu.max_pool3d(_t(x, dev), _t(idx, dev), _t(cnt, dev))
+        np.testing.assert_array_equal(_n(rout), out_o)
+        np.testing.assert_array_equal(_n(rmi), mi_o)
+        np.testing.assert_allclose(_n(ref_gpu.avg_pool3d(_t(x, dev), _t(idx, dev), _t(cnt, dev))), _n(avg), **TOL)
+
+
+@pytest.mark.parametrize("case", POOL_CASES, ids=lambda c: "B%d-N%d-M%d-C%d-K%d" % c)
+def test_unpooling(dev, case):
+    B, N, M, C, K = case
+    rng = np.random.RandomState(C + 100)
+    fine = _clouds("uniform", B, N, seed=C + 2)
+    coarse = fine[:, :M].copy()
+    idx, cnt, dst = oracle.build_sphere_neighbor(coarse, fine, 0.3, None, K)   # db = coarse, query = fine
+    feat = rng.randn(B, M, C).astype(np.float32)
+    go = rng.randn(B, N, C).astype(np.float32)
+    w = (dst + 1e-7) / (dst.sum(-1, keepdims=True) + 1e-7)
+    ft = _t(feat, dev).requires_grad_(True)
+    mean = tf_unpool3d.mean_interpolate(ft, _t(idx, dev), _t(cnt, dev))
+    np.testing.assert_allclose(_n(mean), oracle.mean_interpolate(feat, idx, cnt), **TOL)
+    mean.backward(_t(go, dev))
+    np.testing.assert_allclose(_n(ft.grad), oracle.mean_interpolate_grad(feat, go, idx, cnt), **TOL)
+    ft2 = _t(feat, dev).requires_grad_(True)
+    wi = tf_unpool3d.weighted_interpolate(ft2, _t(w, dev), _t(idx, dev), _t(cnt, dev))
+    np.testing.assert_allclose(_n(wi), oracle.weighted_interpolate(feat, w, idx, cnt), **TOL)
+    wi.backward(_t(go, dev))
+    np.testing.assert_allclose(_n(ft2.grad), oracle.weighted_interpolate_grad(feat, go, w, idx, cnt), **TOL)
+    if ref_gpu.available():
+        np.testing.assert_allclose(_n(ref_gpu.mean_interpolate(_t(feat, dev), _t(idx, dev), _t(cnt, dev))), _n(mean), **TOL)
+        np.testing.assert_allclose(_n(ref_gpu.weighted_interpolate(_t(feat, dev), _t(w, dev), _t(idx, dev), _t(cnt, dev))),
+                                   _n(wi), **TOL)
+
+
+def test_device_scalar_math_matches_host_bitwise(dev):
+    """sqrt / divide are correctly rounded on device and sph3d_atan2f is bit-identical host vs device."""
+    import ctypes
+    rng = np.random.RandomState(1)
+    n = 1 << 20
+    a = (rng.randn(n) * np.exp(rng.randn(n) * 3)).astype(np.float32)
+    b = (rng.randn(n) * np.exp(rng.randn(n) * 3)).astype(np.float32)
+    a[:1000] = np.round(a[:1000] * 33) * 0.03
+    b[:1000] = np.round(b[:1000] * 33) * 0.03
+    at, bt = _t(a, dev), _t(b, dev)
+    o_at = torch.empty(n, device=dev)
+    o_sq = torch.empty(n, device=dev)
+    o_dv = torch.empty(n, device=dev)
+    o_bin = torch.empty(n, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().sph3d_selftest_math(n, _lib.ptr(at), _lib.ptr(bt), _lib.ptr(o_at), _lib.ptr(o_sq),
+                                              _lib.ptr(o_dv), _lib.ptr(o_bin), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(_n(o_sq).view(np.int32), np.sqrt(np.abs(a)).view(np.int32))
+    with np.errstate(all="ignore"):
+        np.testing.assert_array_equal(_n(o_dv).view(np.int32), (a / b).view(np.int32))
+    want = np.arctan2(a.astype(np.float64), b.astype(np.float64)).astype(np.float32)
+    np.testing.assert_array_equal(_n(o_at).view(np.int32), want.view(np.int32))
+    # bins of the full scalar pipeline vs the oracle's C function
+    sb = oracle.lib().oracle_sphere_bin
+    sb.restype = ctypes.c_int
+    got = _n(o_bin)
+    f = ctypes.c_float
+    for i in range(0, 20000):
+        dist = np.sqrt(np.sqrt(np.float32(a[i] * a[i] + b[i] * b[i])))
+        w = sb(f(a[i]), f(b[i]), f(np.float32(a[i] * b[i])), f(dist), f(0.1), 8, 2, 2)
+        assert got[i] == w, i
+
+
+def test_full_size_properties_s3dis_level0(dev):
+    """BASELINE size (B=16, N=M=8192, K=64): size-independent properties instead of the slow oracle:
+    counts in [1,K], ascending indices, zero padding, self is neighbour 0-bin, distances recomputable,
+    bins in range; plus the oracle on a 2-cloud slice (chains do not cross clouds for B <= 32)."""
+    B, N, K, r = 16, 8192, 64, 0.1
+    xyz = synth.s3dis_batch(100, B, N)[0]
+    xt = _t(xyz, dev)
+    idx, cnt, dst = tf_nnquery.build_sphere_neighbor(xt, xt, r, None, K)
+    filt = tf_buildkernel.spherical_kernel(xt, xt, idx, cnt, dst, r, [8, 2, 2])
+    idx_n, cnt_n, dst_n, filt_n = _n(idx), _n(cnt), _n(dst), _n(filt)
+    assert cnt_n.min() >= 1 and cnt_n.max() <= K
+    ar = np.arange(K)[None, None, :]
+    valid = ar < cnt_n[:, :, None]
+    assert (idx_n[~valid] == 0).all() and (dst_n[~valid] == 0).all() and (filt_n[~valid] == 0).all()
+    d = np.diff(idx_n, axis=2)
+    assert (d[valid[:, :, 1:]] > 0).all()
+    assert filt_n.min() >= 0 and filt_n.max() <= 32
+    # every query contains itself (distance 0 -> bin 0)
+    self_hit = ((idx_n == np.arange(N)[None, :, None]) & valid)
+    assert self_hit.any(axis=2).all()
+    assert (filt_n[self_hit] == 0).all()
+    # distances: sqrt(sqrt(d2)) recomputed
+    b_ix = np.arange(B)[:, None, None]
+    nb = xyz[b_ix, idx_n]
+    dd = nb - xyz[:, :, None, :]
+    d2 = (dd[..., 0] * dd[..., 0] + dd[..., 1] * dd[..., 1]) + dd[..., 2] * dd[..., 2]
+    np.testing.assert_array_equal(np.sqrt(np.sqrt(d2))[valid], dst_n[valid])
+    # oracle on two clouds (same chains: B <= 32 so clouds are independent)
+    for b in (0, 15):
+        i_o, c_o, d_o = oracle.build_sphere_neighbor(xyz[b:b + 1], xyz[b:b + 1], r, None, K)
+        np.testing.assert_array_equal(idx_n[b], i_o[0])
+        np.testing.assert_array_equal(cnt_n[b], c_o[0])
+        f_o = oracle.spherical_kernel(xyz[b:b + 1], xyz[b:b + 1], i_o, c_o, d_o, r, [8, 2, 2])
+        np.testing.assert_array_equal(filt_n[b], f_o[0])
+    # FPS at full size: indices distinct (points are distinct), first is 0, matches oracle on one cloud
+    fps = _n(tf_sample.farthest_point_sample(2048, xt))
+    assert (fps[:, 0] == 0).all()
+    for b in range(B):
+        assert len(set(fps[b].tolist())) == 2048
+    np.testing.assert_array_equal(fps[3], oracle.farthest_point_sample(2048, xyz[3:4])[0])
+    # conv at the roofline shape: linearity in the filter and in the input (size-independent property)
+    C, rr = 128, 2
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(B, N, C, generator=g).to(dev)
+    w1 = torch.randn(33, C, rr, generator=g).to(dev)
+    w2 = torch.randn(33, C, rr, generator=g).to(dev)
+    o1 = tf_conv3d.depthwise_conv3d(x, w1, idx, cnt, filt)
+    o2 = tf_conv3d.depthwise_conv3d(x, w2, idx, cnt, filt)
+    o12 = tf_conv3d.depthwise_conv3d(x, w1 + w2, idx, cnt, filt)
+    torch.testing.assert_close(o12, o1 + o2, rtol=1e-4, atol=1e-4)
+    out_o = oracle.depthwise_conv3d(_n(x[:1]), _n(w1), idx_n[:1], cnt_n[:1], filt_n[:1])
+    np.testing.assert_allclose(_n(o1[:1]), out_o, **TOL)
+
+
+def test_empty_and_error_cases(dev):
+    z = torch.zeros((0, 8, 3), device=dev)
+    idx, cnt, dst = tf_nnquery.build_sphere_neighbor(z, z, 0.1, None, 4)
+    assert idx.shape == (0, 8, 4)
+    x = torch.zeros((1, 8, 3), device=dev)
+    with pytest.raises(ValueError):
+        tf_nnquery.build_sphere_neighbor(x, x, -0.1, None, 4)
+    with pytest.raises(ValueError):
+        tf_nnquery.build_sphere_neighbor(x, x, 0.1, None, 0)
+    with pytest.raises(ValueError):
+        tf_sample.farthest_point_sample(0, x)
+    with pytest.raises(ValueError):
+        tf_sample.farthest_point_sample(2, torch.zeros((1, 8, 4), device=dev))
+    idx, cnt, dst = tf_nnquery.build_sphere_neighbor(x, x, 0.1, None, 4)
+    with pytest.raises(ValueError):
+        tf_buildkernel.spherical_kernel(x, x, idx, cnt, dst, 0.1, [3, 2, 2])
+    with pytest.raises(ValueError):
+        tf_conv3d.depthwise_conv3d(torch.zeros((1, 8, 5), device=dev), torch.zeros((33, 4, 2), device=dev), idx, cnt, idx)
