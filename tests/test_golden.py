@@ -1,0 +1,125 @@
+"""The CPU oracle against golden vectors produced by the REFERENCE's own kernels (tf_ops/*/tf_*_gpu.cu compiled
+unmodified with hipcc for gfx950 and run on an MI355X; generator tests/golden/make_golden.py, outputs committed
+as tests/golden/ref_gfx950.{npz,json}).  No GPU needed: inputs are regenerated from seeds and checked by digest.
+
+Bit-exact: nn_index, nn_count, nn_dist, FPS indices, cube indices/bins, max-pool values and arg-max ids.
+filt_index: the reference build used ROCm's ocml atan2f, the oracle the shared correctly-rounded sph3d_atan2f;
+entries may differ only for neighbours sitting on a bin boundary (bounded below; count printed).
+Float activations / gradients (atomically accumulated in the reference): 1e-5.
+"""
+import hashlib
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+def _load_gen():
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return (np.load(os.path.join(GOLD, "ref_gfx950.npz")), json.load(open(os.path.join(GOLD, "ref_gfx950.json"))),
+            _load_gen())
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["tiny", "chain", "decoder", "s3dis2048", "modelnet1024"])
+def test_neighbor_graph_and_bins(gold, name):
+    arr, meta, gen = gold
+    c = gen.cases()[name]
+    d = meta["digests"][name]
+    db = c["db"]
+    q = db if c["q"] is None else c["q"]
+    assert sha(db) == d["db"] and sha(q) == d["q"], "synthetic input generator drifted"
+    idx, cnt, dst = oracle.build_sphere_neighbor(db, q, c["r"], None, c["K"])
+    assert sha(cnt) == d["nn_count"]
+    assert sha(idx) == d["nn_index"]
+    assert sha(dst) == d["nn_dist"]
+    np.testing.assert_array_equal(cnt, arr[name + "/nn_count"])
+    if c["full"]:
+        np.testing.assert_array_equal(idx, arr[name + "/nn_index"])
+        np.testing.assert_array_equal(dst, arr[name + "/nn_dist"])
+    filt = oracle.spherical_kernel(db, q, idx, cnt, dst, c["r"], [8, 2, 2])
+    ref = arr[name + "/filt_index_ocml"].astype(np.int32)
+    mism = np.argwhere(filt != ref)
+    print("%s: filt_index entries differing from the ocml-atan2f reference build: %d of %d" % (name, len(mism), filt.size))
+    assert len(mism) <= max(2, int(1e-4 * filt.size))
+    for b, m, k in mism:      # only the azimuth / elevation cell may move, by one step; never the radial shell or self
+        a, r_ = int(filt[b, m, k]) - 1, int(ref[b, m, k]) - 1
+        assert a >= 0 and r_ >= 0 and a // 16 == r_ // 16
+
+
+def test_chain_case_really_exercises_both_carries(gold):
+    arr, meta, gen = gold
+    cnt = arr["chain/nn_count"].astype(np.int32)       # B=33, M=1100: rows 1024.. and batch 32 use grown radii
+    assert cnt[:32, :1024].mean() < cnt[:32, 1024:].mean()
+    assert cnt[:32, :1024].mean() < cnt[32, :1024].mean()
+
+
+@pytest.mark.parametrize("name", ["fps_s3dis2048", "fps_modelnet10000", "fps_small"])
+def test_fps(gold, name):
+    arr, meta, gen = gold
+    pts, m = gen.fps_cases()[name]
+    assert sha(pts) == meta["digests"][name]["pts"]
+    out = oracle.farthest_point_sample(m, pts)
+    np.testing.assert_array_equal(out, arr[name + "/out"].astype(np.int32))
+    assert sha(out) == meta["digests"][name]["out"]
+
+
+def test_cube(gold):
+    arr, meta, gen = gold
+    from sph3d_gcn_amd.harness import synth
+    db, q = synth.uniform_cloud(8, 2, 300), synth.uniform_cloud(9, 2, 100)
+    idx, cnt = oracle.build_cube_neighbor(db, q, 0.3, None, 8, 3)
+    np.testing.assert_array_equal(idx, arr["cube/nn_index"].astype(np.int32))
+    np.testing.assert_array_equal(cnt, arr["cube/nn_count"].astype(np.int32))
+
+
+def test_feature_ops(gold):
+    arr, meta, gen = gold
+    f = gen.feature_case()
+    db, M, K = f["db"], f["M"], f["K"]
+    q = db[:, :M].copy()
+    idx, cnt, dst = oracle.build_sphere_neighbor(db, q, f["r"], None, K)
+    filt = oracle.spherical_kernel(db, q, idx, cnt, dst, f["r"], [8, 2, 2])
+    np.testing.assert_array_equal(idx, arr["feat/nn_index"])
+    np.testing.assert_array_equal(cnt, arr["feat/nn_count"])
+    gfilt = arr["feat/filt"]            # use the reference build's bins so the float comparison is like for like
+    np.testing.assert_allclose(oracle.depthwise_conv3d(f["x"], f["w"], idx, cnt, gfilt), arr["feat/conv"], **TOL)
+    gi, gf = oracle.depthwise_conv3d_grad(f["x"], f["w"], f["go"], idx, cnt, gfilt)
+    np.testing.assert_allclose(gi, arr["feat/conv_gi"], **TOL)
+    np.testing.assert_allclose(gf, arr["feat/conv_gf"], rtol=1e-5, atol=2e-5)
+    mo, mi = oracle.max_pool3d(f["x"], idx, cnt)
+    np.testing.assert_array_equal(mo, arr["feat/maxpool"])
+    np.testing.assert_array_equal(mi, arr["feat/maxpool_idx"])
+    np.testing.assert_allclose(oracle.max_pool3d_grad(f["x"], f["gp"], mi), arr["feat/maxpool_grad"], **TOL)
+    np.testing.assert_allclose(oracle.avg_pool3d(f["x"], idx, cnt), arr["feat/avgpool"], **TOL)
+    np.testing.assert_allclose(oracle.avg_pool3d_grad(f["x"], f["gp"], idx, cnt), arr["feat/avgpool_grad"], **TOL)
+    uidx, ucnt, udst = oracle.build_sphere_neighbor(q, db, 0.3, None, K)
+    np.testing.assert_array_equal(uidx, arr["feat/un_index"])
+    np.testing.assert_array_equal(ucnt, arr["feat/un_count"])
+    feat = f["x"][:, :M].copy()
+    gu = np.random.RandomState(43).randn(*f["x"].shape).astype(np.float32)
+    wgt = arr["feat/un_weight"]
+    np.testing.assert_allclose(oracle.mean_interpolate(feat, uidx, ucnt), arr["feat/mean"], **TOL)
+    np.testing.assert_allclose(oracle.mean_interpolate_grad(feat, gu, uidx, ucnt), arr["feat/mean_grad"], **TOL)
+    np.testing.assert_allclose(oracle.weighted_interpolate(feat, wgt, uidx, ucnt), arr["feat/weighted"], **TOL)
+    np.testing.assert_allclose(oracle.weighted_interpolate_grad(feat, gu, wgt, uidx, ucnt), arr["feat/weighted_grad"], **TOL)

@@ -72,8 +72,11 @@ def test_sphere_neighbor_and_kernel_bitexact(dev, case):
         f_o = oracle.spherical_kernel(db, q, idx_o, cnt_o, dst_o, radius, [8, 2, 2])
         # the reference build uses ocml's atan2f, ours the shared correctly-rounded one: a last-bit
         # difference can move a neighbour that sits on a bin boundary.  Bound and report.
-        mism = int((rf != f_o).sum())
-        assert mism <= max(2, int(2e-5 * f_o.size)), "filt_index mismatches vs reference build: %d" % mism
+        mism = np.argwhere(rf != f_o)
+        assert len(mism) <= max(2, int(1e-4 * f_o.size)), "filt_index mismatches vs reference build: %d" % len(mism)
+        for b, m, k in mism:   # only the angular cell may move; never self (0) nor the radial shell
+            a, r_ = int(f_o[b, m, k]) - 1, int(rf[b, m, k]) - 1
+            assert a >= 0 and r_ >= 0 and a // 16 == r_ // 16
 
 
 @pytest.mark.parametrize("B,N,M,K,L,G", [(2, 300, 100, 8, 0.3, 3), (1, 1000, 1000, 20, 0.1, 4), (3, 77, 5, 70, 0.9, 2)])
