@@ -95,9 +95,9 @@ int sph3d_depthwise_conv3d(int B, int N, int M, int F, int C, int r, int K,
 /* replaces depthwiseConv3dGradLauncher (tf_conv3d_gpu.cu:115-140; kernels
  * depthwise_input_backward :32-55, depthwise_filter_backward :58-101;
  * op DepthwiseConv3dGrad tf_conv3d.cpp:101-158).
- * grad_input[B,N,C], grad_filter[F,C,r] are fully written (zeroed inside).
- * workspace: sph3d_depthwise_conv3d_grad_workspace() bytes of device memory
- * (may be 0 / NULL when that function returns 0). */
+ * grad_input[B,N,C], grad_filter[F,C,r] are fully written.  The wrapper builds the transposed graph
+ * (below) in `workspace` (sph3d_depthwise_conv3d_grad_workspace() bytes of device memory) and runs
+ * sph3d_depthwise_conv3d_grad_t; callers that keep the transpose across calls use that directly. */
 size_t sph3d_depthwise_conv3d_grad_workspace(int B, int N, int M, int F, int C, int r, int K);
 int sph3d_depthwise_conv3d_grad(int B, int N, int M, int F, int C, int r, int K,
                                 const int* nn_index, const int* nn_count, const int* bin_index,
@@ -105,6 +105,39 @@ int sph3d_depthwise_conv3d_grad(int B, int N, int M, int F, int C, int r, int K,
                                 float* grad_input, float* grad_filter,
                                 void* workspace, size_t workspace_bytes,
                                 sph3d_stream_t stream);
+
+/* ---- transposed neighbour graph (not in the reference: how its atomic scatters are avoided) ----
+ * Every gradient of the path is a scatter over the neighbour graph; libsph3d runs it as a gather over
+ * the graph's transpose ("in-edge lists"), built once per graph and reusable by every gradient that
+ * uses the same (nn_index, nn_count[, bin_index | weight]).  F = number of filter bins (1 when
+ * bin_index is NULL).  In-edges are sorted by (cloud, source point n, bin f):
+ *   offsets[B*(N*F+1)]  edges of segment (b,n,f) are entries [offsets[s], offsets[s+1]), s = b*(N*F+1) + n*F + f
+ *   ent_key[B*M*K]      m, the graph row (output point) the edge comes from
+ *   ent_scale[B*M*K]    1/nn_count[b,m]   (weight[b,m,k] when weight is not NULL)
+ * workspace: sph3d_graph_transpose_workspace() bytes of scratch (segment counters). */
+size_t sph3d_graph_transpose_workspace(int B, int N, int M, int K, int F);
+int sph3d_graph_transpose(int B, int N, int M, int K, int F,
+                          const int* nn_index, const int* nn_count,
+                          const int* bin_index /* or NULL */, const float* weight /* or NULL */,
+                          int* offsets, int* ent_key, float* ent_scale,
+                          void* workspace, size_t workspace_bytes, sph3d_stream_t stream);
+/* conv gradients from a prebuilt transposed graph: both gradients in one pass, no float atomics
+ * (grad_input gathered in registers; grad_filter accumulated in per-lane registers, one partial table per
+ * workgroup written to `workspace` = sph3d_depthwise_conv3d_grad_t_workspace() bytes, then reduced). */
+size_t sph3d_depthwise_conv3d_grad_t_workspace(int B, int N, int F, int C, int r);
+int sph3d_depthwise_conv3d_grad_t(int B, int N, int M, int F, int C, int r,
+                                  const int* offsets, const int* ent_key, const float* ent_scale,
+                                  const float* input, const float* filter, const float* grad_output,
+                                  float* grad_input, float* grad_filter,
+                                  void* workspace, size_t workspace_bytes, sph3d_stream_t stream);
+/* (transposed graph built with F = 1)  grad_input[B,Nin,C] = sum over in-edges of grad_output[B,Mout,C] * ent_scale: the gradient of
+ * avg_pool3d (Nin=N, Mout=M), mean_interpolate and weighted_interpolate (Nin=M coarse, Mout=N fine). */
+int sph3d_scatter_grad_t(int B, int Nin, int Mout, int C,
+                         const int* offsets, const int* ent_key, const float* ent_scale,
+                         const float* grad_output, float* grad_input, sph3d_stream_t stream);
+/* bytes of workspace the *_grad wrappers below need to build the transposed graph internally
+ * (N = number of SOURCE points of the gradient, M = number of graph rows) */
+size_t sph3d_scatter_grad_workspace(int B, int N, int M, int K);
 
 /* ---- pooling ------------------------------------------------------------
  * replaces maxPool3dLauncher / maxPool3dGradLauncher / avgPool3dLauncher /
@@ -122,7 +155,9 @@ int sph3d_avg_pool3d(int B, int N, int M, int C, int K,
                      float* output, sph3d_stream_t stream);
 int sph3d_avg_pool3d_grad(int B, int N, int M, int C, int K,
                           const int* nn_index, const int* nn_count, const float* grad_output,
-                          float* grad_input, sph3d_stream_t stream);
+                          float* grad_input,
+                          void* workspace /* sph3d_scatter_grad_workspace(B,N,M,K) */, size_t workspace_bytes,
+                          sph3d_stream_t stream);
 
 /* ---- unpooling ----------------------------------------------------------
  * replaces meanInterpolateLauncher / meanInterpolateGradLauncher /
@@ -135,7 +170,9 @@ int sph3d_mean_interpolate(int B, int N, int M, int C, int K,
                            float* output, sph3d_stream_t stream);
 int sph3d_mean_interpolate_grad(int B, int N, int M, int C, int K,
                                 const int* nn_index, const int* nn_count, const float* grad_output,
-                                float* grad_input, sph3d_stream_t stream);
+                                float* grad_input,
+                                void* workspace /* sph3d_scatter_grad_workspace(B,M,N,K) */, size_t workspace_bytes,
+                                sph3d_stream_t stream);
 int sph3d_weighted_interpolate(int B, int N, int M, int C, int K,
                                const int* nn_index, const int* nn_count,
                                const float* input, const float* weight,
@@ -143,7 +180,9 @@ int sph3d_weighted_interpolate(int B, int N, int M, int C, int K,
 int sph3d_weighted_interpolate_grad(int B, int N, int M, int C, int K,
                                     const int* nn_index, const int* nn_count,
                                     const float* grad_output, const float* weight,
-                                    float* grad_input, sph3d_stream_t stream);
+                                    float* grad_input,
+                                    void* workspace /* sph3d_scatter_grad_workspace(B,M,N,K) */, size_t workspace_bytes,
+                                    sph3d_stream_t stream);
 
 /* ---- sampling -----------------------------------------------------------
  * replaces farthestPointSampleLauncher (tf_ops/sampling/tf_sample_gpu.cu:77-80;

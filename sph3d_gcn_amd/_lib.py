@@ -32,11 +32,17 @@ SIGNATURES = {
     "sph3d_max_pool3d": (_I, [_I] * 5 + [_P] * 6),
     "sph3d_max_pool3d_grad": (_I, [_I] * 4 + [_P] * 4),
     "sph3d_avg_pool3d": (_I, [_I] * 5 + [_P] * 5),
-    "sph3d_avg_pool3d_grad": (_I, [_I] * 5 + [_P] * 5),
+    "sph3d_avg_pool3d_grad": (_I, [_I] * 5 + [_P] * 4 + [_P, _S, _P]),
+    "sph3d_graph_transpose_workspace": (_S, [_I] * 5),
+    "sph3d_graph_transpose": (_I, [_I] * 5 + [_P] * 7 + [_P, _S, _P]),
+    "sph3d_depthwise_conv3d_grad_t_workspace": (_S, [_I] * 5),
+    "sph3d_depthwise_conv3d_grad_t": (_I, [_I] * 6 + [_P] * 8 + [_P, _S, _P]),
+    "sph3d_scatter_grad_t": (_I, [_I] * 4 + [_P] * 6),
+    "sph3d_scatter_grad_workspace": (_S, [_I] * 4),
     "sph3d_mean_interpolate": (_I, [_I] * 5 + [_P] * 5),
-    "sph3d_mean_interpolate_grad": (_I, [_I] * 5 + [_P] * 5),
+    "sph3d_mean_interpolate_grad": (_I, [_I] * 5 + [_P] * 4 + [_P, _S, _P]),
     "sph3d_weighted_interpolate": (_I, [_I] * 5 + [_P] * 6),
-    "sph3d_weighted_interpolate_grad": (_I, [_I] * 5 + [_P] * 6),
+    "sph3d_weighted_interpolate_grad": (_I, [_I] * 5 + [_P] * 5 + [_P, _S, _P]),
     "sph3d_farthest_point_sample_workspace": (_S, [_I] * 3),
     "sph3d_farthest_point_sample": (_I, [_I] * 3 + [_P, _P, _P, _S, _P]),
     "sph3d_pointwise_gemm": (_I, [_I] * 3 + [_P, _P, _P, _I, _I, _P, _P]),

@@ -1,0 +1,52 @@
+"""Per-graph cache of transposed neighbour graphs (include/sph3d.h: sph3d_graph_transpose).
+
+Every gradient of the path gathers over the transpose of its neighbour graph.  One graph feeds several
+gradients per step (two depthwise convs per level share an intra graph), so the transpose is built once
+per (nn_index, nn_count[, bin_index | weight]) and kept in a small LRU.  An entry holds strong references
+to the tensors it was built from, so their storage (and therefore the data_ptr in the key) cannot be
+recycled for a different graph while the entry is alive; in-place edits are caught by the version counter.
+"""
+import collections
+
+import torch
+
+from . import _lib
+
+_MAX_ENTRIES = 48
+_cache = collections.OrderedDict()
+
+
+def _ident(t):
+    return (0, 0) if t is None else (t.data_ptr(), t._version)
+
+
+def clear():
+    _cache.clear()
+
+
+def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1):
+    """-> (offsets[B*(n_src*F+1)] i32, ent_key[B*M*K] i32, ent_scale[B*M*K] f32) on nn_index's device;
+    F = num_bins (the filter's bin count when bin_index is given, else 1)"""
+    F = int(num_bins) if bin_index is not None else 1
+    key = (_ident(nn_index), _ident(nn_count), _ident(bin_index), _ident(weight), int(n_src), F, tuple(nn_index.shape),
+           torch.cuda.current_stream().cuda_stream)
+    hit = _cache.get(key)
+    if hit is not None:
+        _cache.move_to_end(key)
+        return hit[0]
+    B, M, K = nn_index.shape
+    dev = nn_index.device
+    offsets = torch.empty((B * (n_src * F + 1),), dtype=torch.int32, device=dev)
+    ent_key = torch.empty((B * M * K,), dtype=torch.int32, device=dev)
+    ent_scale = torch.empty((B * M * K,), dtype=torch.float32, device=dev)
+    l = _lib.lib()
+    wsb = l.sph3d_graph_transpose_workspace(B, n_src, M, K, F)
+    ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
+    _lib.check(l.sph3d_graph_transpose(B, n_src, M, K, F, _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(bin_index),
+                                       _lib.ptr(weight), _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale),
+                                       _lib.ptr(ws), wsb, _lib.stream_ptr()))
+    out = (offsets, ent_key, ent_scale)
+    _cache[key] = (out, (nn_index, nn_count, bin_index, weight))
+    while len(_cache) > _MAX_ENTRIES:
+        _cache.popitem(last=False)
+    return out

@@ -12,10 +12,11 @@
 //   * Lanes span output channels, 4 consecutive channels per lane: accumulate in registers, one
 //     coalesced float4 store per point.  A "slice" is 256 output channels; wider layers loop slices.
 //   * The filter table slice (F x 256 floats = 33 KB at F=33) lives in LDS, read as ds_read_b128.
-//   * Backward fuses both gradients in one pass over the graph: grad_input by hardware fp32 atomics
-//     (global_atomic_add_f32), grad_filter into an LDS table with ds_add_f32 (bank-conflict-free
-//     permuted layout), flushed once per workgroup.  The reference re-ran the whole gather
-//     ceil(F*C*r/12288) times (tf_conv3d_gpu.cu:126-139).
+//   * Backward fuses both gradients in ONE pass over the TRANSPOSED graph (graph.hip): grad_input is a
+//     gather (registers, one store per element, no float atomics to memory), grad_filter accumulates in an
+//     LDS table with ds_add_f32 (bank-conflict-free permuted layout), flushed once per workgroup.  The
+//     reference scattered grad_input with one global atomicAdd per (point, neighbour, channel) and re-ran
+//     the whole gather ceil(F*C*r/12288) times for grad_filter (tf_conv3d_gpu.cu:51, 126-139).
 //   * Workgroups of one cloud are dealt to one XCD (xcd_decode) so the cloud's feature rows
 //     (N*C*4 B, 4 MiB at N=8192,C=128) stay in that XCD's 4 MiB L2.
 //   * Numerics: sum_k in*filt in fp32 FMA order k = 0..cnt-1, one division by cnt at the end (the
@@ -26,7 +27,6 @@ namespace sph3d {
 
 constexpr int kSlice = 256;       // output channels per wave pass (64 lanes x 4)
 constexpr int kFwdPointsPerWG = 32;
-constexpr int kBwdPointsPerWG = 64;
 
 // ------------------------------------------------------------------------------------------
 // forward, vectorised: R = depth multiplier (1 or 2), CR % 4 == 0
@@ -173,164 +173,246 @@ __global__ __launch_bounds__(256) void dwconv_fwd_generic(
 }
 
 // ------------------------------------------------------------------------------------------
-// backward, vectorised, both gradients in one pass
-// LDS table gtab holds grad_filter for this slice in a permuted layout:
-//   local channel cl = 4*l + v  ->  gtab[f*SL + v*(SL/4) + l]   (consecutive lanes -> consecutive banks)
+// backward over the TRANSPOSED graph (graph.hip): one wave per source point n, NO float atomics in the loop.
+// Per in-edge (m, scale) of segment (n, f): one coalesced gather of grad_out[b,m, V channels/lane]; per segment one
+// LDS read of the filter row; with g = grad_out * scale (scale = 1/nn_count[m]):
+//     grad_in[b,n,c]     += sum_rho g * filt[f,c,rho]     registers, stored once per element
+//     grad_filt[f,c,rho] += g * in[b,n,c]                 REGISTERS: every lane keeps a private [MAXF][V]
+//                                                         accumulator; the transposed graph is sorted by
+//                                                         (n, bin), so the kernel walks the F segments of a
+//                                                         source in a fully unrolled loop: acc[f] is a fixed
+//                                                         register, the filter row is read once per segment
+//                                                         ("gather / segment-sum").
+// Round-1 measurement that forced this shape: the same loop with the table in LDS updated by ds_add_f32
+// ran 12.4 ms at (B=16, N=8192, C=128, r=2); without those LDS float atomics 1.4 ms — ds_add_f32 retires
+// roughly one LANE per 4 cycles on gfx950.  Global fp32 atomics (the reference's scheme) were 9.0 ms.
+// At the end the 4 waves of a workgroup sum their accumulators through LDS with plain reads/writes (taking
+// turns), and the workgroup writes ONE partial table to a workspace slab; reduce_filter_partials adds the slabs.
+// V = channels per lane: 4 for F <= 33 (the [8,2,2] and [8,2,1] kernels), 2 for F <= 65 ([8,2,3] = 49 bins).
+// Edges are consumed four at a time: four scalar key loads and four independent row gathers are issued before
+// any is used (memory-level parallelism; the kernel is latency-bound at 2 waves/SIMD otherwise).
 // ------------------------------------------------------------------------------------------
-template <int R>
-__global__ __launch_bounds__(256) void dwconv_bwd_vec(
-    int B, int N, int M, int F, int C, int K, int mblocks, int nslices,
-    const int* __restrict__ nnIndex, const int* __restrict__ nnCount, const int* __restrict__ binIndex,
+constexpr int kBwdTWaves = 4;
+constexpr int kBwdTPointsPerWG = 128;
+
+template <int R, int V, int MAXF>
+__global__ __launch_bounds__(kBwdTWaves * 64) void dwconv_bwd_t_vec(
+    int B, int N, int M, int F, int C, int nblocks, int nslices,
+    const int* __restrict__ offsets, const int* __restrict__ entKey, const float* __restrict__ entScale,
     const float* __restrict__ input, const float* __restrict__ filter, const float* __restrict__ gradOutput,
-    float* __restrict__ gradInput, float* __restrict__ gradFilter)
+    float* __restrict__ gradInput, float* __restrict__ partial)
 {
-    extern __shared__ __attribute__((aligned(16))) float gtab[];   // [F][SL] permuted
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int SLW = 64 * V;                 // slice width in output channels
+    constexpr int VI = (V >= R) ? V / R : 1;    // input channels per lane
     const int CR = C * R;
     int b, part;
-    xcd_decode((int)blockIdx.x, B, mblocks * nslices, b, part);
+    xcd_decode((int)blockIdx.x, B, nblocks * nslices, b, part);
     if (b < 0) return;
-    const int slice = part / mblocks;
-    const int mb = part - slice * mblocks;
-    const int slice0 = slice * kSlice;
-    const int SL = (CR - slice0) < kSlice ? (CR - slice0) : kSlice;
-    const int SLQ = SL >> 2;
+    const int slice = part / nblocks;
+    const int nb = part - slice * nblocks;
+    const int slice0 = slice * SLW;
+    const int SL = (CR - slice0) < SLW ? (CR - slice0) : SLW;     // multiple of V
+    float* lfilt = lds;                                           // [F][SL]
 
-    for (int e = threadIdx.x; e < F * SL; e += blockDim.x) gtab[e] = 0.f;
+    for (int e = threadIdx.x * V; e < F * SL; e += blockDim.x * V) {
+        const int f = e / SL;
+        const int cl = e - f * SL;
+#pragma unroll
+        for (int v = 0; v < V; v++) lfilt[e + v] = filter[(size_t)f * CR + slice0 + cl + v];
+    }
     __syncthreads();
 
     const int wave = uniform((int)threadIdx.x >> 6);
     const int lane = lane_id();
-    const int cl0 = lane * 4;
+    const int cl0 = lane * V;
     const bool act = cl0 < SL;
     const int cin0 = (slice0 + cl0) / R;
-    const int m_begin = mb * kBwdPointsPerWG;
-    const int m_end = (m_begin + kBwdPointsPerWG) < M ? (m_begin + kBwdPointsPerWG) : M;
-    const float* inb = input + (size_t)b * N * C;
-    float* ginb = gradInput + (size_t)b * N * C;
+    const int n_begin = nb * kBwdTPointsPerWG;
+    const int n_end = (n_begin + kBwdTPointsPerWG) < N ? (n_begin + kBwdTPointsPerWG) : N;
+    const float* gob = gradOutput + (size_t)b * M * CR + slice0 + cl0;
+    const int* __restrict__ offb = offsets + (size_t)b * ((size_t)N * F + 1);
 
-    for (int m = m_begin + wave; m < m_end; m += 4) {
-        const size_t row = (size_t)b * M + m;
-        const int cnt = uniform(nnCount[row]);
-        if (cnt <= 0) continue;
-        float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (act) {
-            go = *reinterpret_cast<const float4*>(&gradOutput[row * CR + slice0 + cl0]);
-            const float fc = (float)cnt;
-            go.x /= fc; go.y /= fc; go.z /= fc; go.w /= fc;     // the reference's /nnSize (:50, :87)
-        }
-        const int* __restrict__ irow = nnIndex + row * K;   // wave-uniform address -> scalar loads
-        const int* __restrict__ brow = binIndex + row * K;
-        {
-#pragma unroll 4
-            for (int kk = 0; kk < cnt; kk++) {
-                const int n = irow[kk];
-                const int f = brow[kk];
-                if (act) {
-                    const float4 w = *reinterpret_cast<const float4*>(&filter[(size_t)f * CR + slice0 + cl0]);
-                    float* gt = &gtab[f * SL + lane];
-                    if (R == 2) {
-                        const float2 x = *reinterpret_cast<const float2*>(&inb[(size_t)n * C + cin0]);
-                        unsafeAtomicAdd(&ginb[(size_t)n * C + cin0], fmaf(go.x, w.x, go.y * w.y));
-                        unsafeAtomicAdd(&ginb[(size_t)n * C + cin0 + 1], fmaf(go.z, w.z, go.w * w.w));
-                        unsafeAtomicAdd(gt, go.x * x.x);
-                        unsafeAtomicAdd(gt + SLQ, go.y * x.x);
-                        unsafeAtomicAdd(gt + 2 * SLQ, go.z * x.y);
-                        unsafeAtomicAdd(gt + 3 * SLQ, go.w * x.y);
-                    } else {
-                        const float4 x = *reinterpret_cast<const float4*>(&inb[(size_t)n * C + cin0]);
-                        unsafeAtomicAdd(&ginb[(size_t)n * C + cin0], go.x * w.x);
-                        unsafeAtomicAdd(&ginb[(size_t)n * C + cin0 + 1], go.y * w.y);
-                        unsafeAtomicAdd(&ginb[(size_t)n * C + cin0 + 2], go.z * w.z);
-                        unsafeAtomicAdd(&ginb[(size_t)n * C + cin0 + 3], go.w * w.w);
-                        unsafeAtomicAdd(gt, go.x * x.x);
-                        unsafeAtomicAdd(gt + SLQ, go.y * x.y);
-                        unsafeAtomicAdd(gt + 2 * SLQ, go.z * x.z);
-                        unsafeAtomicAdd(gt + 3 * SLQ, go.w * x.w);
+    // per-lane gradient-of-filter accumulators, one row per bin; every index below is a compile-time constant
+    // (the bin loop is fully unrolled), so the table lives in VGPRs
+    float acc[MAXF][V];
+#pragma unroll
+    for (int i = 0; i < MAXF; i++)
+#pragma unroll
+        for (int v = 0; v < V; v++) acc[i][v] = 0.f;
+
+    for (int n = n_begin + wave; n < n_end; n += kBwdTWaves) {
+        const int* __restrict__ o = offb + (size_t)n * F;      // F+1 consecutive segment bounds: scalar loads
+        float xi[VI], xv[V];
+#pragma unroll
+        for (int u = 0; u < VI; u++) xi[u] = act ? input[((size_t)b * N + n) * C + cin0 + u] : 0.f;
+#pragma unroll
+        for (int v = 0; v < V; v++) xv[v] = xi[(V >= R) ? v / R : 0];
+        float gi[V];
+#pragma unroll
+        for (int v = 0; v < V; v++) gi[v] = 0.f;
+#pragma unroll
+        for (int f = 0; f < MAXF; f++) {
+            if (f < F) {
+                const int e0 = o[f], e1 = o[f + 1];
+                if (e0 < e1) {                               // wave-uniform: most (n, bin) segments are empty or short
+                    float sg[V];
+#pragma unroll
+                    for (int v = 0; v < V; v++) sg[v] = 0.f;
+                    for (int e = e0; e < e1; e += 4) {
+                        // four edges at a time: their row gathers are independent and issued together
+                        int mm[4];
+                        float sc[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int ee = (e + u) < e1 ? (e + u) : (e1 - 1);
+                            mm[u] = entKey[ee];
+                            sc[u] = (e + u) < e1 ? entScale[ee] : 0.f;      // padding edges contribute exactly 0
+                        }
+                        float g[4][V];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+#pragma unroll
+                            for (int v = 0; v < V; v++) g[u][v] = 0.f;
+                            if (act) {
+                                if (V == 4) {
+                                    const float4 t = *reinterpret_cast<const float4*>(&gob[(size_t)mm[u] * CR]);
+                                    g[u][0] = t.x; g[u][1 % V] = t.y; g[u][2 % V] = t.z; g[u][3 % V] = t.w;
+                                } else if (V == 2) {
+                                    const float2 t = *reinterpret_cast<const float2*>(&gob[(size_t)mm[u] * CR]);
+                                    g[u][0] = t.x; g[u][1 % V] = t.y;
+                                } else {
+                                    g[u][0] = gob[(size_t)mm[u] * CR];
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+#pragma unroll
+                            for (int v = 0; v < V; v++) sg[v] = fmaf(g[u][v], sc[u], sg[v]);
+                    }
+                    const float* wrow = &lfilt[f * SL + (act ? cl0 : 0)];
+#pragma unroll
+                    for (int v = 0; v < V; v++) {
+                        gi[v] = fmaf(sg[v], wrow[v], gi[v]);
+                        acc[f][v] = fmaf(sg[v], xv[v], acc[f][v]);
                     }
                 }
             }
         }
+        if (act) {
+            float* gp = &gradInput[((size_t)b * N + n) * C + cin0];
+            if (V >= R) {
+#pragma unroll
+                for (int u = 0; u < VI; u++) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int rr = 0; rr < R; rr++) s += gi[u * R + rr];
+                    gp[u] = s;
+                }
+            }
+        }
     }
-    __syncthreads();
-    // flush: un-permute, skip untouched entries (many bins are never hit at small radii)
+
+    // workgroup reduction of the per-wave accumulators: waves take turns on one [F][SL] LDS table
+    __syncthreads();                 // everyone is done reading lfilt
+    float* tab = lds;                // reuse: [F][SL]
+    for (int w = 0; w < kBwdTWaves; w++) {
+        if (wave == w && act) {
+#pragma unroll
+            for (int i = 0; i < MAXF; i++) {
+                if (i < F) {
+#pragma unroll
+                    for (int v = 0; v < V; v++) {
+                        float* p = &tab[i * SL + cl0 + v];
+                        *p = (w == 0) ? acc[i][v] : (*p + acc[i][v]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* out = partial + ((size_t)b * nblocks + nb) * ((size_t)F * CR);
     for (int e = threadIdx.x; e < F * SL; e += blockDim.x) {
         const int f = e / SL;
-        const int pe = e - f * SL;          // permuted position v*SLQ + l
-        const int v = pe / SLQ;
-        const int l = pe - v * SLQ;
-        const float g = gtab[e];
-        if (g != 0.f) unsafeAtomicAdd(&gradFilter[(size_t)f * CR + slice0 + 4 * l + v], g);
+        const int cl = e - f * SL;
+        out[(size_t)f * CR + slice0 + cl] = tab[e];
     }
 }
 
-// backward, generic (any C, r)
-__global__ __launch_bounds__(256) void dwconv_bwd_generic(
-    int B, int N, int M, int F, int C, int r, int K, int mblocks, int nslices,
-    const int* __restrict__ nnIndex, const int* __restrict__ nnCount, const int* __restrict__ binIndex,
+// grad_filter[j] = sum over the B*nblocks partial tables, fixed order -> deterministic given the partials
+__global__ __launch_bounds__(256) void reduce_filter_partials(int nparts, int total, const float* __restrict__ partial,
+                                                              float* __restrict__ gradFilter)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+    for (; p + 4 <= nparts; p += 4) {
+        s0 += partial[(size_t)p * total + j];
+        s1 += partial[(size_t)(p + 1) * total + j];
+        s2 += partial[(size_t)(p + 2) * total + j];
+        s3 += partial[(size_t)(p + 3) * total + j];
+    }
+    for (; p < nparts; p++) s0 += partial[(size_t)p * total + j];
+    gradFilter[j] = (s0 + s1) + (s2 + s3);
+}
+
+// generic transposed backward (any C, r <= 256): lanes own INPUT channels c_base + lane + 64*t,
+// a slice is SC = min(C - c_base, max(1, 256 / r)) input channels; LDS table [F][SC*r]
+__global__ __launch_bounds__(256) void dwconv_bwd_t_generic(
+    int B, int N, int M, int F, int C, int r, int nblocks, int nslices, int sliceC,
+    const int* __restrict__ offsets, const int* __restrict__ entKey, const float* __restrict__ entScale,
     const float* __restrict__ input, const float* __restrict__ filter, const float* __restrict__ gradOutput,
     float* __restrict__ gradInput, float* __restrict__ gradFilter)
 {
-    extern __shared__ __attribute__((aligned(16))) float gtab[];   // [F][SL]
+    extern __shared__ __attribute__((aligned(16))) float gtab[];
     const int CR = C * r;
     int b, part;
-    xcd_decode((int)blockIdx.x, B, mblocks * nslices, b, part);
+    xcd_decode((int)blockIdx.x, B, nblocks * nslices, b, part);
     if (b < 0) return;
-    const int slice = part / mblocks;
-    const int mb = part - slice * mblocks;
-    const int slice0 = slice * kSlice;
-    const int SL = (CR - slice0) < kSlice ? (CR - slice0) : kSlice;
-
-    for (int e = threadIdx.x; e < F * SL; e += blockDim.x) gtab[e] = 0.f;
+    const int slice = part / nblocks;
+    const int nb = part - slice * nblocks;
+    const int c_base = slice * sliceC;
+    const int SC = (C - c_base) < sliceC ? (C - c_base) : sliceC;
+    const int SW = SC * r;
+    for (int e = threadIdx.x; e < F * SW; e += blockDim.x) gtab[e] = 0.f;
     __syncthreads();
 
     const int wave = uniform((int)threadIdx.x >> 6);
     const int lane = lane_id();
-    int cl[4], cin[4];
-    bool act[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        cl[t] = lane + 64 * t;
-        act[t] = cl[t] < SL;
-        cin[t] = act[t] ? (slice0 + cl[t]) / r : 0;
-        if (!act[t]) cl[t] = 0;
-    }
-    const int m_begin = mb * kBwdPointsPerWG;
-    const int m_end = (m_begin + kBwdPointsPerWG) < M ? (m_begin + kBwdPointsPerWG) : M;
-    const float* inb = input + (size_t)b * N * C;
-    float* ginb = gradInput + (size_t)b * N * C;
-
-    for (int m = m_begin + wave; m < m_end; m += 4) {
-        const size_t row = (size_t)b * M + m;
-        const int cnt = uniform(nnCount[row]);
-        if (cnt <= 0) continue;
-        float go[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) go[t] = act[t] ? gradOutput[row * CR + slice0 + cl[t]] / (float)cnt : 0.f;
-        const int* __restrict__ irow = nnIndex + row * K;   // wave-uniform address -> scalar loads
-        const int* __restrict__ brow = binIndex + row * K;
-        {
-#pragma unroll 4
-            for (int kk = 0; kk < cnt; kk++) {
-                const int n = irow[kk];
-                const int f = brow[kk];
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    if (act[t]) {
-                        const float x = inb[(size_t)n * C + cin[t]];
-                        const float w = filter[(size_t)f * CR + slice0 + cl[t]];
-                        unsafeAtomicAdd(&ginb[(size_t)n * C + cin[t]], go[t] * w);
-                        unsafeAtomicAdd(&gtab[f * SL + cl[t]], go[t] * x);
-                    }
+    const int n_begin = nb * 64;
+    const int n_end = (n_begin + 64) < N ? (n_begin + 64) : N;
+    const int* __restrict__ offb = offsets + (size_t)b * ((size_t)N * F + 1);
+    for (int n = n_begin + wave; n < n_end; n += 4) {
+        const int* __restrict__ o = offb + (size_t)n * F;
+        for (int t = 0; t < 4; t++) {
+            const int cl = lane + 64 * t;
+            if (cl >= SC) break;
+            const int cin = c_base + cl;
+            const float x = input[((size_t)b * N + n) * C + cin];
+            float gi = 0.f;
+            for (int f = 0; f < F; f++) {
+                const int e0 = o[f], e1 = o[f + 1];
+                if (e0 >= e1) continue;
+                for (int rr = 0; rr < r; rr++) {
+                    const int cout = cin * r + rr;
+                    float sg = 0.f;
+                    for (int e = e0; e < e1; e++)
+                        sg = fmaf(gradOutput[((size_t)b * M + entKey[e]) * CR + cout], entScale[e], sg);
+                    gi = fmaf(sg, filter[(size_t)f * CR + cout], gi);
+                    unsafeAtomicAdd(&gtab[f * SW + cl * r + rr], sg * x);     // one LDS atomic per (segment, channel)
                 }
             }
+            gradInput[((size_t)b * N + n) * C + cin] = gi;
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < F * SL; e += blockDim.x) {
-        const int f = e / SL;
-        const int c = e - f * SL;
+    for (int e = threadIdx.x; e < F * SW; e += blockDim.x) {
+        const int f = e / SW;
+        const int j = e - f * SW;
         const float g = gtab[e];
-        if (g != 0.f) unsafeAtomicAdd(&gradFilter[(size_t)f * CR + slice0 + c], g);
+        if (g != 0.f) unsafeAtomicAdd(&gradFilter[(size_t)f * CR + c_base * r + j], g);
     }
 }
 
@@ -385,7 +467,125 @@ extern "C" int sph3d_depthwise_conv3d(int B, int N, int M, int F, int C, int r, 
     return check_launch("sph3d_depthwise_conv3d");
 }
 
-extern "C" size_t sph3d_depthwise_conv3d_grad_workspace(int, int, int, int, int, int, int) { return 0; }
+// layout of the transposed graph inside a caller-provided workspace
+struct TGraphWs {
+    int* offsets; int* key; float* scale; void* scratch; size_t scratch_bytes;
+};
+static size_t tgraph_ws_bytes(int B, int N, int M, int K, int F)
+{
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    return al(sizeof(int) * (size_t)B * ((size_t)N * F + 1)) + 2 * al(sizeof(int) * (size_t)B * M * K) +
+           al(sizeof(int) * (size_t)B * N * F);
+}
+static TGraphWs tgraph_carve(void* ws, int B, int N, int M, int K, int F)
+{
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    char* p = (char*)ws;
+    TGraphWs t;
+    t.offsets = (int*)p; p += al(sizeof(int) * (size_t)B * ((size_t)N * F + 1));
+    t.key = (int*)p; p += al(sizeof(int) * (size_t)B * M * K);
+    t.scale = (float*)p; p += al(sizeof(int) * (size_t)B * M * K);
+    t.scratch = p; t.scratch_bytes = al(sizeof(int) * (size_t)B * N * F);
+    return t;
+}
+
+extern "C" size_t sph3d_scatter_grad_workspace(int B, int N, int M, int K) { return tgraph_ws_bytes(B, N, M, K, 1); }
+extern "C" size_t sph3d_depthwise_conv3d_grad_t_workspace(int B, int N, int F, int C, int r);
+extern "C" size_t sph3d_depthwise_conv3d_grad_workspace(int B, int N, int M, int F, int C, int r, int K)
+{
+    return tgraph_ws_bytes(B, N, M, K, F) + sph3d_depthwise_conv3d_grad_t_workspace(B, N, F, C, r);
+}
+
+static int vec_plan(int F, int CR, int r, int& V)
+{
+    if (!(r == 1 || r == 2)) return 0;
+    if (F <= 33 && CR % 4 == 0) { V = 4; return 1; }
+    if (F <= 65 && CR % 2 == 0) { V = 2; return 1; }
+    return 0;
+}
+
+extern "C" size_t sph3d_depthwise_conv3d_grad_t_workspace(int B, int N, int F, int C, int r)
+{
+    int V = 0;
+    if (!vec_plan(F, C * r, r, V)) return 0;
+    const int nblocks = (N + kBwdTPointsPerWG - 1) / kBwdTPointsPerWG;
+    return sizeof(float) * (size_t)B * nblocks * F * C * r;
+}
+
+template <int R, int V, int MAXF>
+static int launch_bwd_t_vec(int B, int N, int M, int F, int C, const int* offsets, const int* ent_key,
+                            const float* ent_scale, const float* input, const float* filter,
+                            const float* grad_output, float* grad_input, float* grad_filter, float* partial,
+                            hipStream_t st)
+{
+    const int CR = C * R;
+    const int nblocks = (N + kBwdTPointsPerWG - 1) / kBwdTPointsPerWG;
+    const int SLW = 64 * V;
+    const int nslices = (CR + SLW - 1) / SLW;
+    const int SLmax = CR < SLW ? CR : SLW;
+    const size_t lds = (size_t)F * SLmax * sizeof(float);
+    auto kern = dwconv_bwd_t_vec<R, V, MAXF>;
+    if (lds > 64 * 1024) {
+        int rc = check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                           "conv3d: hipFuncSetAttribute");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(kern, dim3(xcd_grid(B, nblocks * nslices)), dim3(kBwdTWaves * 64), lds, st, B, N, M, F, C,
+                       nblocks, nslices, offsets, ent_key, ent_scale, input, filter, grad_output, grad_input, partial);
+    const int total = F * CR;
+    hipLaunchKernelGGL(reduce_filter_partials, dim3((total + 255) / 256), dim3(256), 0, st, B * nblocks, total, partial,
+                       grad_filter);
+    return check_launch("sph3d_depthwise_conv3d_grad_t");
+}
+
+extern "C" int sph3d_depthwise_conv3d_grad_t(int B, int N, int M, int F, int C, int r,
+                                             const int* offsets, const int* ent_key, const float* ent_scale,
+                                             const float* input, const float* filter, const float* grad_output,
+                                             float* grad_input, float* grad_filter,
+                                             void* workspace, size_t workspace_bytes, sph3d_stream_t stream)
+{
+    int rc = conv_dims_ok(B, N, M, F, C, r, 1, "DepthwiseConv3dGrad");
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    const int CR = C * r;
+    if (B == 0) return check_hip(hipMemsetAsync(grad_filter, 0, sizeof(float) * (size_t)F * CR, st), "conv3d grad: memset");
+    int V = 0;
+    if (vec_plan(F, CR, r, V)) {
+        const size_t need = sph3d_depthwise_conv3d_grad_t_workspace(B, N, F, C, r);
+        if (workspace == nullptr || workspace_bytes < need) {
+            set_error("DepthwiseConv3dGrad: workspace %zu B < required %zu B", workspace_bytes, need);
+            return SPH3D_EWORKSPACE;
+        }
+        float* partial = (float*)workspace;
+#define SPH3D_GO(RR, VV, MF) \
+    return launch_bwd_t_vec<RR, VV, MF>(B, N, M, F, C, offsets, ent_key, ent_scale, input, filter, grad_output, \
+                                        grad_input, grad_filter, partial, st)
+        if (V == 4 && r == 2) SPH3D_GO(2, 4, 33);
+        if (V == 4 && r == 1) SPH3D_GO(1, 4, 33);
+        if (V == 2 && r == 2) SPH3D_GO(2, 2, 65);
+        SPH3D_GO(1, 2, 65);
+#undef SPH3D_GO
+    }
+    // generic path (odd channel counts, other multipliers, F > 64): LDS float atomics, slow but general
+    rc = check_hip(hipMemsetAsync(grad_filter, 0, sizeof(float) * (size_t)F * CR, st), "conv3d grad: memset");
+    if (rc) return rc;
+    SPH3D_REQUIRE(r <= 256, "DepthwiseConv3dGrad: depth multiplier %d > 256 unsupported", r);
+    int sliceC = 256 / r;
+    if (sliceC < 1) sliceC = 1;
+    if (sliceC > C) sliceC = C;
+    const int nslices = (C + sliceC - 1) / sliceC;
+    const int nblocks = (N + 63) / 64;
+    const size_t lds = (size_t)F * sliceC * r * sizeof(float);
+    if (lds > 64 * 1024) {
+        rc = check_hip(hipFuncSetAttribute((const void*)dwconv_bwd_t_generic, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds), "conv3d: hipFuncSetAttribute");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(dwconv_bwd_t_generic, dim3(xcd_grid(B, nblocks * nslices)), dim3(256), lds, st, B, N, M, F, C, r,
+                       nblocks, nslices, sliceC, offsets, ent_key, ent_scale, input, filter, grad_output, grad_input,
+                       grad_filter);
+    return check_launch("sph3d_depthwise_conv3d_grad_t");
+}
 
 extern "C" int sph3d_depthwise_conv3d_grad(int B, int N, int M, int F, int C, int r, int K,
                                            const int* nn_index, const int* nn_count, const int* bin_index,
@@ -393,37 +593,20 @@ extern "C" int sph3d_depthwise_conv3d_grad(int B, int N, int M, int F, int C, in
                                            float* grad_input, float* grad_filter,
                                            void* workspace, size_t workspace_bytes, sph3d_stream_t stream)
 {
-    (void)workspace; (void)workspace_bytes;
     int rc = conv_dims_ok(B, N, M, F, C, r, K, "DepthwiseConv3dGrad");
     if (rc) return rc;
-    hipStream_t st = as_stream(stream);
-    const int CR = C * r;
-    // the op zero-fills both gradients first (tf_conv3d.cpp:152-153)
-    rc = check_hip(hipMemsetAsync(grad_filter, 0, sizeof(float) * (size_t)F * CR, st), "conv3d grad: memset");
-    if (rc) return rc;
-    if (B == 0) return SPH3D_OK;
-    rc = check_hip(hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)B * N * C, st), "conv3d grad: memset");
-    if (rc) return rc;
-    if (M == 0) return SPH3D_OK;
-    const int mblocks = (M + kBwdPointsPerWG - 1) / kBwdPointsPerWG;
-    const int nslices = (CR + kSlice - 1) / kSlice;
-    const int SLmax = CR < kSlice ? CR : kSlice;
-    const size_t lds = (size_t)F * SLmax * sizeof(float);
-    const dim3 grid(xcd_grid(B, mblocks * nslices));
-    const bool vec = (CR % 4 == 0) && (r == 1 || r == 2);
-    if (vec && r == 2) {
-        SPH3D_BIG_LDS(dwconv_bwd_vec<2>)
-        hipLaunchKernelGGL(dwconv_bwd_vec<2>, grid, dim3(256), lds, st, B, N, M, F, C, K, mblocks, nslices,
-                           nn_index, nn_count, bin_index, input, filter, grad_output, grad_input, grad_filter);
-    } else if (vec) {
-        SPH3D_BIG_LDS(dwconv_bwd_vec<1>)
-        hipLaunchKernelGGL(dwconv_bwd_vec<1>, grid, dim3(256), lds, st, B, N, M, F, C, K, mblocks, nslices,
-                           nn_index, nn_count, bin_index, input, filter, grad_output, grad_input, grad_filter);
-    } else {
-        SPH3D_BIG_LDS(dwconv_bwd_generic)
-        hipLaunchKernelGGL(dwconv_bwd_generic, grid, dim3(256), lds, st, B, N, M, F, C, r, K, mblocks, nslices,
-                           nn_index, nn_count, bin_index, input, filter, grad_output, grad_input, grad_filter);
+    const size_t tg = tgraph_ws_bytes(B, N, M, K, F);
+    const size_t need = tg + sph3d_depthwise_conv3d_grad_t_workspace(B, N, F, C, r);
+    if (B > 0 && (workspace == nullptr || workspace_bytes < need)) {
+        set_error("DepthwiseConv3dGrad: workspace %zu B < required %zu B", workspace_bytes, need);
+        return SPH3D_EWORKSPACE;
     }
-    return check_launch("sph3d_depthwise_conv3d_grad");
-#undef SPH3D_BIG_LDS
+    if (B == 0) return sph3d_depthwise_conv3d_grad_t(B, N, M, F, C, r, nullptr, nullptr, nullptr, input, filter,
+                                                     grad_output, grad_input, grad_filter, nullptr, 0, stream);
+    TGraphWs t = tgraph_carve(workspace, B, N, M, K, F);
+    rc = sph3d_graph_transpose(B, N, M, K, F, nn_index, nn_count, bin_index, nullptr, t.offsets, t.key, t.scale,
+                               t.scratch, t.scratch_bytes, stream);
+    if (rc) return rc;
+    return sph3d_depthwise_conv3d_grad_t(B, N, M, F, C, r, t.offsets, t.key, t.scale, input, filter, grad_output,
+                                         grad_input, grad_filter, (char*)workspace + tg, workspace_bytes - tg, stream);
 }

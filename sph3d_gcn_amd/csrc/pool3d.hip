@@ -5,12 +5,13 @@
 //
 // All eight kernels are the same shape of work — "for every output point, walk its neighbour list and
 // combine gathered feature rows" — so they share one skeleton: one wavefront per output point, the
-// neighbour row fetched once (lane k = slot k) and broadcast with v_readlane, lanes spanning channels
+// neighbour row read through the scalar cache (its address is wave-uniform), lanes spanning channels
 // with float4 (or scalar when C % 4 != 0) coalesced row reads, accumulation in registers, one store.
 // The reference used one thread per (point, channel) with a global read-modify-write per neighbour
 // and a cudaDeviceSynchronize after every launch (tf_pool3d_gpu.cu:97,104,111,118).
 // Un-pooling "mean" is avg-pooling with the roles of the point sets swapped, so it reuses that kernel.
-// Scatter gradients use hardware fp32 atomics (global_atomic_add_f32).
+// avg / mean / weighted gradients gather over the transposed graph (graph.hip); only the max-pool gradient
+// (one element per output, data-dependent target) still uses hardware fp32 atomics.
 #include "common.hpp"
 
 namespace sph3d {
@@ -89,51 +90,53 @@ __global__ __launch_bounds__(256) void gather_fwd(
     }
 }
 
-// scatter gradient of avg-pool / mean- and weighted-interpolate:
-//   gradInput[b, idx_k, c] += gradOutput[b, m, c] * (1/cnt  or  w_k)
-template <Mode MODE, int V>
-__global__ __launch_bounds__(256) void scatter_bwd(
-    int B, int Nin, int Mout, int C, int K, int mblocks,
-    const int* __restrict__ nnIndex, const int* __restrict__ nnCount,
-    const float* __restrict__ gradOutput, const float* __restrict__ weight,
-    float* __restrict__ gradInput)
+// gradient of avg-pool / mean- and weighted-interpolate as a GATHER over the transposed graph (graph.hip):
+//   gradInput[b, n, c] = sum over in-edges (m, scale) of gradOutput[b, m, c] * scale
+// scale = 1/nn_count[m] (avg / mean) or weight[b,m,k] (weighted).  One wave per source point n, each
+// gradInput element written exactly once: no atomics, no memset (the reference: atomicAdd per
+// (point, neighbour, channel), tf_pool3d_gpu.cu:86, tf_unpool3d_gpu.cu:38,80).
+template <int V>
+__global__ __launch_bounds__(256) void gather_bwd_t(
+    int B, int Nin, int Mout, int C, int nblocks,
+    const int* __restrict__ offsets, const int* __restrict__ entKey, const float* __restrict__ entScale,
+    const float* __restrict__ gradOutput, float* __restrict__ gradInput)
 {
-    int b, mb;
-    xcd_decode((int)blockIdx.x, B, mblocks, b, mb);
+    int b, nb;
+    xcd_decode((int)blockIdx.x, B, nblocks, b, nb);
     if (b < 0) return;
     const int wave = uniform((int)threadIdx.x >> 6);
     const int lane = lane_id();
-    const int m_begin = mb * kPtsPerWG;
-    const int m_end = (m_begin + kPtsPerWG) < Mout ? (m_begin + kPtsPerWG) : Mout;
-    float* ginb = gradInput + (size_t)b * Nin * C;
-
-    for (int m = m_begin + wave; m < m_end; m += 4) {
-        const size_t row = (size_t)b * Mout + m;
-        const int cnt = uniform(nnCount[row]);
-        if (cnt <= 0) continue;
+    const int n_begin = nb * kPtsPerWG;
+    const int n_end = (n_begin + kPtsPerWG) < Nin ? (n_begin + kPtsPerWG) : Nin;
+    const float* gob = gradOutput + (size_t)b * Mout * C;
+    const int* __restrict__ offb = offsets + (size_t)b * (Nin + 1);
+    for (int n = n_begin + wave; n < n_end; n += 4) {
+        const int e0 = offb[n], e1 = offb[n + 1];
         for (int c0 = 0; c0 < C; c0 += 64 * V) {
             const int c = c0 + lane * V;
             const bool act = c < C;
-            float go[V];
+            float acc[V];
 #pragma unroll
-            for (int v = 0; v < V; v++) {
-                go[v] = act ? gradOutput[row * C + c + v] : 0.f;
-                if (MODE == Mode::Avg) go[v] = go[v] / (float)cnt;      // tf_pool3d_gpu.cu:86
-            }
-            const int* __restrict__ irow = nnIndex + row * K;   // wave-uniform address -> scalar loads
-            const float* __restrict__ wrow = weight + row * K;
-            {
+            for (int v = 0; v < V; v++) acc[v] = 0.f;
 #pragma unroll 4
-                for (int kk = 0; kk < cnt; kk++) {
-                    const int n = irow[kk];
-                    float w = 1.f;
-                    if (MODE == Mode::Weighted) w = wrow[kk];
-                    if (act) {
-#pragma unroll
-                        for (int v = 0; v < V; v++)
-                            unsafeAtomicAdd(&ginb[(size_t)n * C + c + v], MODE == Mode::Weighted ? go[v] * w : go[v]);
+            for (int e = e0; e < e1; e++) {
+                const int m = entKey[e];
+                const float sc = entScale[e];
+                if (act) {
+                    if (V == 4) {
+                        const float4 t = *reinterpret_cast<const float4*>(&gob[(size_t)m * C + c]);
+                        acc[0] = fmaf(t.x, sc, acc[0]);
+                        acc[1 % V] = fmaf(t.y, sc, acc[1 % V]);
+                        acc[2 % V] = fmaf(t.z, sc, acc[2 % V]);
+                        acc[3 % V] = fmaf(t.w, sc, acc[3 % V]);
+                    } else {
+                        acc[0] = fmaf(gob[(size_t)m * C + c], sc, acc[0]);
                     }
                 }
+            }
+            if (act) {
+#pragma unroll
+                for (int v = 0; v < V; v++) gradInput[((size_t)b * Nin + n) * C + c + v] = acc[v];
             }
         }
     }
@@ -174,25 +177,20 @@ static int launch_fwd(const char* who, int B, int Nin, int Mout, int C, int K,
     return check_launch(who);
 }
 
-template <Mode MODE>
-static int launch_bwd(const char* who, int B, int Nin, int Mout, int C, int K,
-                      const int* nn_index, const int* nn_count, const float* grad_output, const float* weight,
-                      float* grad_input, hipStream_t st)
+static int launch_bwd_t(const char* who, int B, int Nin, int Mout, int C,
+                        const int* offsets, const int* ent_key, const float* ent_scale,
+                        const float* grad_output, float* grad_input, hipStream_t st)
 {
-    SPH3D_REQUIRE(B >= 0 && Nin > 0 && Mout >= 0 && C > 0 && K > 0, "%s: bad dims B=%d N=%d M=%d C=%d K=%d",
-                  who, B, Nin, Mout, C, K);
+    SPH3D_REQUIRE(B >= 0 && Nin > 0 && Mout >= 0 && C > 0, "%s: bad dims B=%d N=%d M=%d C=%d", who, B, Nin, Mout, C);
     if (B == 0) return SPH3D_OK;
-    int rc = check_hip(hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)B * Nin * C, st), who);
-    if (rc) return rc;
-    if (Mout == 0) return SPH3D_OK;
-    const int mblocks = (Mout + kPtsPerWG - 1) / kPtsPerWG;
-    const dim3 grid(xcd_grid(B, mblocks));
+    const int nblocks = (Nin + kPtsPerWG - 1) / kPtsPerWG;
+    const dim3 grid(xcd_grid(B, nblocks));
     if (C % 4 == 0)
-        hipLaunchKernelGGL((scatter_bwd<MODE, 4>), grid, dim3(256), 0, st, B, Nin, Mout, C, K, mblocks,
-                           nn_index, nn_count, grad_output, weight, grad_input);
+        hipLaunchKernelGGL(gather_bwd_t<4>, grid, dim3(256), 0, st, B, Nin, Mout, C, nblocks, offsets, ent_key,
+                           ent_scale, grad_output, grad_input);
     else
-        hipLaunchKernelGGL((scatter_bwd<MODE, 1>), grid, dim3(256), 0, st, B, Nin, Mout, C, K, mblocks,
-                           nn_index, nn_count, grad_output, weight, grad_input);
+        hipLaunchKernelGGL(gather_bwd_t<1>, grid, dim3(256), 0, st, B, Nin, Mout, C, nblocks, offsets, ent_key,
+                           ent_scale, grad_output, grad_input);
     return check_launch(who);
 }
 
@@ -230,11 +228,47 @@ extern "C" int sph3d_avg_pool3d(int B, int N, int M, int C, int K, const int* nn
                                  nullptr, as_stream(stream));
 }
 
-extern "C" int sph3d_avg_pool3d_grad(int B, int N, int M, int C, int K, const int* nn_index, const int* nn_count,
-                                     const float* grad_output, float* grad_input, sph3d_stream_t stream)
+// ---- gradients: transposed-graph entry point + the reference-surface wrappers that build the transpose ----
+
+
+// grad_input[B,Nin,C] = gather over in-edges of grad_output[B,Mout,C] * scale
+extern "C" int sph3d_scatter_grad_t(int B, int Nin, int Mout, int C, const int* offsets, const int* ent_key,
+                                    const float* ent_scale, const float* grad_output, float* grad_input,
+                                    sph3d_stream_t stream)
 {
-    return launch_bwd<Mode::Avg>("sph3d_avg_pool3d_grad", B, N, M, C, K, nn_index, nn_count, grad_output, nullptr,
-                                 grad_input, as_stream(stream));
+    return launch_bwd_t("sph3d_scatter_grad_t", B, Nin, Mout, C, offsets, ent_key, ent_scale, grad_output, grad_input,
+                        as_stream(stream));
+}
+
+static int grad_via_transpose(const char* who, int B, int Nin, int Mout, int C, int K, const int* nn_index,
+                              const int* nn_count, const float* weight, const float* grad_output, float* grad_input,
+                              void* workspace, size_t workspace_bytes, sph3d_stream_t stream)
+{
+    SPH3D_REQUIRE(B >= 0 && Nin > 0 && Mout >= 0 && C > 0 && K > 0, "%s: bad dims B=%d N=%d M=%d C=%d K=%d", who, B,
+                  Nin, Mout, C, K);
+    if (B == 0) return SPH3D_OK;
+    const size_t need = sph3d_scatter_grad_workspace(B, Nin, Mout, K);
+    if (workspace == nullptr || workspace_bytes < need) {
+        set_error("%s: workspace %zu B < required %zu B", who, workspace_bytes, need);
+        return SPH3D_EWORKSPACE;
+    }
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    char* p = (char*)workspace;
+    int* offsets = (int*)p; p += al(sizeof(int) * (size_t)B * (Nin + 1));
+    int* key = (int*)p; p += al(sizeof(int) * (size_t)B * Mout * K);
+    float* scale = (float*)p; p += al(sizeof(int) * (size_t)B * Mout * K);
+    int rc = sph3d_graph_transpose(B, Nin, Mout, K, 1, nn_index, nn_count, nullptr, weight, offsets, key, scale, p,
+                                   al(sizeof(int) * (size_t)B * Nin), stream);
+    if (rc) return rc;
+    return launch_bwd_t(who, B, Nin, Mout, C, offsets, key, scale, grad_output, grad_input, as_stream(stream));
+}
+
+extern "C" int sph3d_avg_pool3d_grad(int B, int N, int M, int C, int K, const int* nn_index, const int* nn_count,
+                                     const float* grad_output, float* grad_input,
+                                     void* workspace, size_t workspace_bytes, sph3d_stream_t stream)
+{
+    return grad_via_transpose("sph3d_avg_pool3d_grad", B, N, M, C, K, nn_index, nn_count, nullptr, grad_output,
+                              grad_input, workspace, workspace_bytes, stream);
 }
 
 // un-pooling: the reference's N is the fine (output) count and M the coarse (input) count
@@ -247,10 +281,10 @@ extern "C" int sph3d_mean_interpolate(int B, int N, int M, int C, int K, const i
 
 extern "C" int sph3d_mean_interpolate_grad(int B, int N, int M, int C, int K, const int* nn_index,
                                            const int* nn_count, const float* grad_output, float* grad_input,
-                                           sph3d_stream_t stream)
+                                           void* workspace, size_t workspace_bytes, sph3d_stream_t stream)
 {
-    return launch_bwd<Mode::Avg>("sph3d_mean_interpolate_grad", B, M, N, C, K, nn_index, nn_count, grad_output,
-                                 nullptr, grad_input, as_stream(stream));
+    return grad_via_transpose("sph3d_mean_interpolate_grad", B, /*Nin=*/M, /*Mout=*/N, C, K, nn_index, nn_count, nullptr,
+                              grad_output, grad_input, workspace, workspace_bytes, stream);
 }
 
 extern "C" int sph3d_weighted_interpolate(int B, int N, int M, int C, int K, const int* nn_index,
@@ -263,8 +297,9 @@ extern "C" int sph3d_weighted_interpolate(int B, int N, int M, int C, int K, con
 
 extern "C" int sph3d_weighted_interpolate_grad(int B, int N, int M, int C, int K, const int* nn_index,
                                                const int* nn_count, const float* grad_output, const float* weight,
-                                               float* grad_input, sph3d_stream_t stream)
+                                               float* grad_input, void* workspace, size_t workspace_bytes,
+                                               sph3d_stream_t stream)
 {
-    return launch_bwd<Mode::Weighted>("sph3d_weighted_interpolate_grad", B, M, N, C, K, nn_index, nn_count,
-                                      grad_output, weight, grad_input, as_stream(stream));
+    return grad_via_transpose("sph3d_weighted_interpolate_grad", B, M, N, C, K, nn_index, nn_count, weight, grad_output,
+                              grad_input, workspace, workspace_bytes, stream);
 }

@@ -7,12 +7,13 @@
 //     also defines its tie-break); their xyz AND running min-distance live in registers for the whole
 //     kernel (the reference re-read a global `temp` array and 3072-point shared cache every round);
 //   * per round each thread updates its P points and keeps its best (value, candidate xyz);
-//   * the wave arg-max is a 6-step butterfly on a packed 64-bit key
-//       key = order_preserving(float bits of value) << 32 | (1023 - t) << 8 | p
-//     so "larger value, then lower thread id" is one unsigned max — exactly the reference's tree
-//     (:56-66, left entry wins ties) composed with its strict > per-thread scan (:49);
-//   * one LDS slot per wave {key, x, y, z}, double-buffered -> ONE barrier per round (reference: 11),
-//     after which every thread reads the <= 16 slots and knows the winner and its coordinates.
+//   * the wave arg-max is a 6-instruction DPP max (row shifts + row broadcasts, no LDS) of the
+//     order-preserving float bits, then ballot(value == max) + count-trailing-zeros picks the LOWEST lane:
+//     "larger value, then lower thread id" — exactly the reference's tree (:56-66, left entry wins ties)
+//     composed with its strict > per-thread scan (:49);
+//   * one 16-byte LDS slot per wave {value bits, x, y, z}, double-buffered -> ONE barrier per round
+//     (reference: 11); after it each wave loads the 16 slots with ONE ds_read_b128 (lane l reads slot l&15),
+//     repeats the DPP max + ballot inside the row and readlanes the winner's coordinates.
 //   * race-free by construction (the reference reads dists_i[0] unfenced at :68).
 // Clouds larger than 1024 * 24 points fall back to a kernel that keeps the running distance in a
 // caller-provided workspace (the reference's `temp`) and re-reads xyz from L2.
@@ -25,6 +26,20 @@ __device__ __forceinline__ unsigned order_bits(float v)
 {
     const unsigned u = __float_as_uint(v);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// wave64 max of an unsigned value with DPP row shifts + row broadcasts (gfx9 scan idiom: 6 VALU ops, no LDS);
+// the result is valid in lane 63 and returned as a wave-uniform scalar.  Identity 0.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+    unsigned t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); v = v > t ? v : t;   // row_shr:1
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); v = v > t ? v : t;   // row_shr:2
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); v = v > t ? v : t;   // row_shr:4
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); v = v > t ? v : t;   // row_shr:8
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); v = v > t ? v : t;   // row_bcast:15
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); v = v > t ? v : t;   // row_bcast:31
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m)
@@ -40,11 +55,18 @@ struct __attribute__((aligned(16))) FpsSlot {
     int pad[3];
 };
 
+// one 16-byte LDS slot per wave and round: ordered value bits + the candidate's coordinates
+struct __attribute__((aligned(16))) FpsSlot16 {
+    unsigned vbits;
+    float x, y, z;
+};
+
 template <int P>
 __global__ __launch_bounds__(1024) void fps_reg_kernel(int b, int n, int m,
                                                        const float* __restrict__ dataset, int* __restrict__ idxs)
 {
-    __shared__ FpsSlot slots[2][16];
+    __shared__ FpsSlot16 slots[2][16];
+    __shared__ int slot_k[2][16];           // the candidate's point index, read by thread 0 only
     const int t = (int)threadIdx.x;
     const int lane = t & 63;
     const int wave = uniform(t >> 6);
@@ -60,11 +82,14 @@ __global__ __launch_bounds__(1024) void fps_reg_kernel(int b, int n, int m,
             px[p] = ok ? pts[k * 3] : 0.f;
             py[p] = ok ? pts[k * 3 + 1] : 0.f;
             pz[p] = ok ? pts[k * 3 + 2] : 0.f;
-            td[p] = 1e38f;                                   // tf_sample_gpu.cu:19-21
+            td[p] = ok ? 1e38f : -1.f;      // tf_sample_gpu.cu:19-21; absent points can never win (best starts at -1)
         }
         float x1 = pts[0], y1 = pts[1], z1 = pts[2];         // old = 0 (:16)
         if (t == 0) idxs[(size_t)i * m] = 0;
-        __syncthreads();   // slots of the previous cloud are no longer read
+        if (t < 32) {                                        // unused slots never win
+            slots[t >> 4][t & 15].vbits = 0u;
+        }
+        __syncthreads();
 
         for (int j = 1; j < m; j++) {
             float best = -1.f;                               // :27-28
@@ -72,52 +97,36 @@ __global__ __launch_bounds__(1024) void fps_reg_kernel(int b, int n, int m,
             float bx = 0.f, by = 0.f, bz = 0.f;
 #pragma unroll
             for (int p = 0; p < P; p++) {
-                const int k = t + p * kRefBlock;
-                if (k < n) {
-                    const float dx = px[p] - x1, dy = py[p] - y1, dz = pz[p] - z1;
-                    const float d = (dx * dx + dy * dy) + dz * dz;       // :45
-                    const float d2 = d < td[p] ? d : td[p];              // :46 min(d, td)
-                    td[p] = d2;
-                    if (d2 > best) { best = d2; bestp = p; bx = px[p]; by = py[p]; bz = pz[p]; }   // :49
-                }
+                const float dx = px[p] - x1, dy = py[p] - y1, dz = pz[p] - z1;
+                const float d = (dx * dx + dy * dy) + dz * dz;           // :45
+                const float d2 = d < td[p] ? d : td[p];                  // :46 min(d, td); absent points stay -1
+                td[p] = d2;
+                if (d2 > best) { best = d2; bestp = p; bx = px[p]; by = py[p]; bz = pz[p]; }   // :49 strict >
             }
-            // idle threads (t >= n) keep best = -1, besti = 0: they can only win if nobody else exists
-            unsigned long long key = ((unsigned long long)order_bits(best) << 32) |
-                                     ((unsigned)(kRefBlock - 1 - t) << 8) | (unsigned)bestp;
-            unsigned long long wk = key;
-#pragma unroll
-            for (int s = 1; s < 64; s <<= 1) {
-                const unsigned long long o = shfl_xor_u64(wk, s);
-                wk = o > wk ? o : wk;
-            }
+            // wave arg-max: max value, then lowest lane (= lowest reference thread id in this wave)
+            const unsigned vb = order_bits(best);
+            const unsigned wmax = wave_max_u32(vb);
+            const unsigned long long tie = __ballot(vb == wmax);
+            const int wl = (int)__builtin_ctzll(tie);
             const int buf = j & 1;
-            if (key == wk) {   // exactly one lane: thread ids are distinct
-                FpsSlot sl;
-                sl.key = key; sl.x = bx; sl.y = by; sl.z = bz;
-                slots[buf][wave].key = sl.key;
-                slots[buf][wave].x = sl.x;
-                slots[buf][wave].y = sl.y;
-                slots[buf][wave].z = sl.z;
+            if (lane == wl) {
+                FpsSlot16 sl;
+                sl.vbits = vb; sl.x = bx; sl.y = by; sl.z = bz;
+                slots[buf][wave] = sl;
+                slot_k[buf][wave] = (best >= 0.f) ? (t + bestp * kRefBlock) : 0;   // idle thread: besti = 0
             }
             __syncthreads();
-            unsigned long long gk = slots[buf][0].key;
-            int gw = 0;
-            for (int w = 1; w < nwaves; w++) {
-                const unsigned long long o = slots[buf][w].key;
-                if (o > gk) { gk = o; gw = w; }
-            }
-            x1 = slots[buf][gw].x;
-            y1 = slots[buf][gw].y;
-            z1 = slots[buf][gw].z;
-            if (t == 0) {
-                const int wt = kRefBlock - 1 - (int)((gk >> 8) & 0x3ffu);
-                const int wp = (int)(gk & 0xffu);
-                // an idle-thread winner (best = -1) reports besti = 0 like the reference
-                const int wi = (wt < n) ? wt + wp * kRefBlock : 0;
-                idxs[(size_t)i * m + j] = wi;
-            }
+            // every wave: lanes 0..15 read the 16 slots, reduce inside the row, lowest wave wins ties
+            const FpsSlot16 s = slots[buf][lane & 15];
+            const unsigned gmax = wave_max_u32(s.vbits);
+            const unsigned long long gt = __ballot(s.vbits == gmax);
+            const int gw = (int)__builtin_ctzll(gt);          // < 16: lanes 0..15 hold slots 0..15
+            x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.x), gw));
+            y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.y), gw));
+            z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.z), gw));
+            if (t == 0) idxs[(size_t)i * m + j] = slot_k[buf][gw];
+            (void)nwaves;
         }
-        (void)lane;
     }
 }
 

@@ -7,7 +7,7 @@ from typing import Tuple
 
 import torch
 
-from . import _lib
+from . import _lib, _tgraph
 
 
 def _check_pool(input, nn_index, nn_count):
@@ -95,8 +95,9 @@ def _avg_pool3d_grad(input: torch.Tensor, grad_output: torch.Tensor, nn_index: t
     B, N, C = input.shape
     M, K = nn_index.shape[1], nn_index.shape[2]
     grad_input = torch.empty((B, N, C), dtype=torch.float32, device=input.device)
-    _lib.check(_lib.lib().sph3d_avg_pool3d_grad(B, N, M, C, K, _lib.ptr(nn_index), _lib.ptr(nn_count),
-                                                _lib.ptr(grad_output), _lib.ptr(grad_input), _lib.stream_ptr()))
+    offsets, ent_key, ent_scale = _tgraph.transpose(nn_index, nn_count, N)
+    _lib.check(_lib.lib().sph3d_scatter_grad_t(B, N, M, C, _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale),
+                                               _lib.ptr(grad_output), _lib.ptr(grad_input), _lib.stream_ptr()))
     return grad_input
 
 

@@ -5,7 +5,7 @@ As in the reference (:21-28) ``weight`` receives no gradient.
 """
 import torch
 
-from . import _lib
+from . import _lib, _tgraph
 
 
 def _check(input, nn_index, nn_count):
@@ -43,9 +43,9 @@ def _mean_interpolate_grad(input: torch.Tensor, grad_output: torch.Tensor, nn_in
     B, M, C = input.shape
     N, K = nn_index.shape[1], nn_index.shape[2]
     grad_input = torch.empty((B, M, C), dtype=torch.float32, device=input.device)
-    _lib.check(_lib.lib().sph3d_mean_interpolate_grad(B, N, M, C, K, _lib.ptr(nn_index), _lib.ptr(nn_count),
-                                                      _lib.ptr(grad_output), _lib.ptr(grad_input),
-                                                      _lib.stream_ptr()))
+    offsets, ent_key, ent_scale = _tgraph.transpose(nn_index, nn_count, M)      # source points = the M coarse points
+    _lib.check(_lib.lib().sph3d_scatter_grad_t(B, M, N, C, _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale),
+                                               _lib.ptr(grad_output), _lib.ptr(grad_input), _lib.stream_ptr()))
     return grad_input
 
 
@@ -96,9 +96,9 @@ def _weighted_interpolate_grad(input: torch.Tensor, grad_output: torch.Tensor, w
     B, M, C = input.shape
     N, K = nn_index.shape[1], nn_index.shape[2]
     grad_input = torch.empty((B, M, C), dtype=torch.float32, device=input.device)
-    _lib.check(_lib.lib().sph3d_weighted_interpolate_grad(B, N, M, C, K, _lib.ptr(nn_index), _lib.ptr(nn_count),
-                                                          _lib.ptr(grad_output), _lib.ptr(weight),
-                                                          _lib.ptr(grad_input), _lib.stream_ptr()))
+    offsets, ent_key, ent_scale = _tgraph.transpose(nn_index, nn_count, M, weight=weight)
+    _lib.check(_lib.lib().sph3d_scatter_grad_t(B, M, N, C, _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale),
+                                               _lib.ptr(grad_output), _lib.ptr(grad_input), _lib.stream_ptr()))
     return grad_input
 
 

@@ -274,7 +274,7 @@ def test_full_size_properties_s3dis_level0(dev):
     assert filt_n.min() >= 0 and filt_n.max() <= 32
     # every query contains itself (distance 0 -> bin 0)
     self_hit = ((idx_n == np.arange(N)[None, :, None]) & valid)
-    assert self_hit.any(axis=2).all()
+    assert self_hit.any(axis=2)[cnt_n < K].all()      # (a saturated list keeps the 64 lowest indices, maybe not self)
     assert (filt_n[self_hit] == 0).all()
     # distances: sqrt(sqrt(d2)) recomputed
     b_ix = np.arange(B)[:, None, None]
@@ -327,3 +327,53 @@ def test_empty_and_error_cases(dev):
         tf_buildkernel.spherical_kernel(x, x, idx, cnt, dst, 0.1, [3, 2, 2])
     with pytest.raises(ValueError):
         tf_conv3d.depthwise_conv3d(torch.zeros((1, 8, 5), device=dev), torch.zeros((33, 4, 2), device=dev), idx, cnt, idx)
+
+
+def test_cabi_gradient_wrappers_with_workspace(dev):
+    """The reference-surface gradient entry points (which build the transposed graph in a caller workspace)
+    called straight through the C ABI, plus the too-small-workspace error path."""
+    import ctypes
+    B, N, M, C, r, K = 2, 150, 60, 12, 2, 16
+    rng = np.random.RandomState(5)
+    db, q, idx, cnt, dst, filt = _graph("uniform", B, N, M, K, 0.25, seed=77)
+    x = rng.randn(B, N, C).astype(np.float32)
+    w = rng.randn(33, C, r).astype(np.float32)
+    go = rng.randn(B, M, C * r).astype(np.float32)
+    gp = rng.randn(B, M, C).astype(np.float32)
+    l = _lib.lib()
+    P = _lib.ptr
+    xt, wt, got, gpt = _t(x, dev), _t(w, dev), _t(go, dev), _t(gp, dev)
+    it, ct, ft = _t(idx, dev), _t(cnt, dev), _t(filt, dev)
+    gi = torch.empty_like(xt)
+    gf = torch.empty_like(wt)
+    wsb = l.sph3d_depthwise_conv3d_grad_workspace(B, N, M, 33, C, r, K)
+    assert wsb > 0
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    rc = l.sph3d_depthwise_conv3d_grad(B, N, M, 33, C, r, K, P(it), P(ct), P(ft), P(xt), P(wt), P(got), P(gi), P(gf),
+                                       P(ws), wsb, _lib.stream_ptr())
+    assert rc == 0
+    gi_o, gf_o = oracle.depthwise_conv3d_grad(x, w, go, idx, cnt, filt)
+    np.testing.assert_allclose(_n(gi), gi_o, **TOL)
+    np.testing.assert_allclose(_n(gf), gf_o, rtol=1e-5, atol=2e-5)
+    rc = l.sph3d_depthwise_conv3d_grad(B, N, M, 33, C, r, K, P(it), P(ct), P(ft), P(xt), P(wt), P(got), P(gi), P(gf),
+                                       P(ws), 16, _lib.stream_ptr())
+    assert rc == -2 and b"workspace" in l.sph3d_last_error()
+    wsb = l.sph3d_scatter_grad_workspace(B, N, M, K)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    g2 = torch.empty_like(xt)
+    assert l.sph3d_avg_pool3d_grad(B, N, M, C, K, P(it), P(ct), P(gpt), P(g2), P(ws), wsb, _lib.stream_ptr()) == 0
+    np.testing.assert_allclose(_n(g2), oracle.avg_pool3d_grad(x, gp, idx, cnt), **TOL)
+    # un-pooling wrappers: N fine points, M coarse
+    uidx, ucnt, udst = oracle.build_sphere_neighbor(q, db, 0.3, None, K)
+    wgt = ((udst + 1e-7) / (udst.sum(-1, keepdims=True) + 1e-7)).astype(np.float32)
+    feat = x[:, :M].copy()
+    gu = rng.randn(B, N, C).astype(np.float32)
+    ut, uct, wgt_t, gut = _t(uidx, dev), _t(ucnt, dev), _t(wgt, dev), _t(gu, dev)
+    wsb = l.sph3d_scatter_grad_workspace(B, M, N, K)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    g3 = torch.empty((B, M, C), device=dev)
+    assert l.sph3d_mean_interpolate_grad(B, N, M, C, K, P(ut), P(uct), P(gut), P(g3), P(ws), wsb, _lib.stream_ptr()) == 0
+    np.testing.assert_allclose(_n(g3), oracle.mean_interpolate_grad(feat, gu, uidx, ucnt), **TOL)
+    assert l.sph3d_weighted_interpolate_grad(B, N, M, C, K, P(ut), P(uct), P(gut), P(wgt_t), P(g3), P(ws), wsb,
+                                             _lib.stream_ptr()) == 0
+    np.testing.assert_allclose(_n(g3), oracle.weighted_interpolate_grad(feat, gu, wgt, uidx, ucnt), **TOL)
