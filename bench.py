@@ -86,8 +86,7 @@ def make_batch(rank, dev):
 
 def train_step(model, flat, opt, pts, label, inner):
     flat.zero()
-    graphs = s3dis_net.build_graphs(pts, model.config)
-    pred, _ = model(pts, is_training=True, graphs=graphs)
+    pred, _ = model(pts, is_training=True)          # graphs are built level by level inside (GraphPlan)
     loss = model.loss(pred, label, inner)
     loss.backward()
     flat.all_reduce()

@@ -475,7 +475,7 @@ static size_t tgraph_ws_bytes(int B, int N, int M, int K, int F)
 {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     return al(sizeof(int) * (size_t)B * ((size_t)N * F + 1)) + 2 * al(sizeof(int) * (size_t)B * M * K) +
-           al(sizeof(int) * (size_t)B * N * F);
+           al(sph3d_graph_transpose_workspace(B, N, M, K, F));
 }
 static TGraphWs tgraph_carve(void* ws, int B, int N, int M, int K, int F)
 {
@@ -485,7 +485,7 @@ static TGraphWs tgraph_carve(void* ws, int B, int N, int M, int K, int F)
     t.offsets = (int*)p; p += al(sizeof(int) * (size_t)B * ((size_t)N * F + 1));
     t.key = (int*)p; p += al(sizeof(int) * (size_t)B * M * K);
     t.scale = (float*)p; p += al(sizeof(int) * (size_t)B * M * K);
-    t.scratch = p; t.scratch_bytes = al(sizeof(int) * (size_t)B * N * F);
+    t.scratch = p; t.scratch_bytes = al(sph3d_graph_transpose_workspace(B, N, M, K, F));
     return t;
 }
 

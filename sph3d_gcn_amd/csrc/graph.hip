@@ -15,7 +15,7 @@
 //                      ("gather / segment-sum"); cloud b owns the slab [b*M*K, (b+1)*M*K) of the entry arrays
 //   ent_key[B*M*K]     m, the graph row (output point) of the edge
 //   ent_scale[B*M*K]   1/nn_count[m]  (or weight[b,m,k] when a weight array is given)
-// Built in three passes: in-degree count (integer atomics), per-cloud exclusive scan, fill (integer atomic
+// Built in three steps: segment count (integer atomics), per-cloud exclusive scan, fill (integer atomic
 // cursor).  The fill order within one list is not deterministic, so float sums may differ in the last bits
 // between runs — as with the reference's atomics, but without their cost.
 #include "common.hpp"
@@ -40,36 +40,88 @@ __global__ __launch_bounds__(256) void tg_count(int B, int N, int M, int K, int 
     }
 }
 
-// one 1024-thread block per cloud: offsets = b*M*K + exclusive scan of deg; deg is cleared for reuse as cursor
-__global__ __launch_bounds__(1024) void tg_scan(int N, int MK, int* __restrict__ deg, int* __restrict__ offsets)
+// Exclusive scan of the per-cloud counter arrays (L = N*F counters per cloud) in three fully parallel passes:
+//   tg_chunk_sums : one 256-thread block per chunk of kChunk counters -> its sum
+//   tg_scan_sums  : one block per cloud scans its (<= 1024) chunk sums in LDS
+//   tg_apply      : every chunk re-scans itself from its base, writes offsets and clears the counters (they
+//                   become the fill cursors)
+constexpr int kChunk = 2048;
+
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int* lds, int& total)
 {
-    __shared__ int part[1024];
-    const int b = (int)blockIdx.x;
+    // 256 threads; returns the exclusive prefix of v, total = block sum
     const int t = (int)threadIdx.x;
-    int* d = deg + (size_t)b * N;
-    int* off = offsets + (size_t)b * (N + 1);
-    const int per = (N + 1023) / 1024;
-    const int lo = t * per;
-    const int hi = (lo + per) < N ? (lo + per) : N;
-    int s = 0;
-    for (int i = lo; i < hi; i++) s += d[i];
-    part[t] = s;
+    lds[t] = v;
     __syncthreads();
-    // Hillis-Steele inclusive scan over the 1024 partial sums
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int v = (t >= o) ? part[t - o] : 0;
+    for (int o = 1; o < 256; o <<= 1) {
+        const int a = (t >= o) ? lds[t - o] : 0;
         __syncthreads();
-        part[t] += v;
+        lds[t] += a;
         __syncthreads();
     }
-    int run = b * MK + (t > 0 ? part[t - 1] : 0);
-    for (int i = lo; i < hi; i++) {
-        const int c = d[i];
-        off[i] = run;
-        run += c;
-        d[i] = 0;
+    const int incl = lds[t];
+    total = lds[255];
+    __syncthreads();
+    return incl - v;
+}
+
+__global__ __launch_bounds__(256) void tg_chunk_sums(int L, int chunks, const int* __restrict__ deg, int* __restrict__ sums)
+{
+    __shared__ int lds[256];
+    const int b = (int)blockIdx.x / chunks, c = (int)blockIdx.x % chunks;
+    const int* d = deg + (size_t)b * L;
+    const int lo = c * kChunk;
+    int s = 0;
+    for (int i = lo + (int)threadIdx.x; i < lo + kChunk && i < L; i += 256) s += d[i];
+    int total;
+    block_exclusive_scan_256(s, lds, total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void tg_scan_sums(int chunks, int MK, int* __restrict__ sums)
+{
+    __shared__ int lds[256];
+    const int b = (int)blockIdx.x;
+    int* s = sums + (size_t)b * chunks;
+    int run = b * MK;                      // cloud b owns the entry slab starting at b*M*K
+    for (int base = 0; base < chunks; base += 256) {
+        const int i = base + (int)threadIdx.x;
+        const int v = i < chunks ? s[i] : 0;
+        int total;
+        const int ex = block_exclusive_scan_256(v, lds, total);
+        if (i < chunks) s[i] = run + ex;
+        run += total;
     }
-    if (t == 1023) off[N] = b * MK + part[1023];
+}
+
+__global__ __launch_bounds__(256) void tg_apply(int L, int chunks, int* __restrict__ deg, const int* __restrict__ sums,
+                                                int* __restrict__ offsets)
+{
+    __shared__ int lds[256];
+    const int b = (int)blockIdx.x / chunks, c = (int)blockIdx.x % chunks;
+    int* d = deg + (size_t)b * L;
+    int* off = offsets + (size_t)b * ((size_t)L + 1);
+    const int lo = c * kChunk;
+    constexpr int PER = kChunk / 256;
+    const int t0 = lo + (int)threadIdx.x * PER;
+    int v[PER];
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        v[j] = (t0 + j) < L ? d[t0 + j] : 0;
+        s += v[j];
+    }
+    int total;
+    int run = sums[blockIdx.x] + block_exclusive_scan_256(s, lds, total);
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        if ((t0 + j) < L) {
+            off[t0 + j] = run;
+            d[t0 + j] = 0;
+        }
+        run += v[j];
+    }
+    if (c == chunks - 1 && threadIdx.x == 255) off[L] = run;     // end of the cloud's last segment
 }
 
 __global__ __launch_bounds__(256) void tg_fill(int B, int N, int M, int K, int F, const int* __restrict__ nnIndex,
@@ -107,7 +159,8 @@ using namespace sph3d;
 extern "C" size_t sph3d_graph_transpose_workspace(int B, int N, int M, int K, int F)
 {
     (void)M; (void)K;
-    return sizeof(int) * (size_t)B * N * F;
+    const size_t L = (size_t)N * F;
+    return sizeof(int) * ((size_t)B * L + (size_t)B * ((L + kChunk - 1) / kChunk));
 }
 
 extern "C" int sph3d_graph_transpose(int B, int N, int M, int K, int F,
@@ -127,14 +180,19 @@ extern "C" int sph3d_graph_transpose(int B, int N, int M, int K, int F,
     }
     hipStream_t st = as_stream(stream);
     int* deg = (int*)workspace;
-    int rc = check_hip(hipMemsetAsync(deg, 0, need, st), "graph_transpose: memset");
+    int rc = check_hip(hipMemsetAsync(deg, 0, sizeof(int) * (size_t)B * N * F, st), "graph_transpose: memset");
     if (rc) return rc;
     const long long total = (long long)B * M * K;
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     if (total > 0)
         hipLaunchKernelGGL(tg_count, dim3((unsigned)blocks), dim3(256), 0, st, B, N, M, K, F, nn_index, nn_count, bin_index, deg);
-    hipLaunchKernelGGL(tg_scan, dim3(B), dim3(1024), 0, st, N * F, M * K, deg, offsets);
+    const int L = N * F;
+    const int chunks = (L + kChunk - 1) / kChunk;
+    int* sums = deg + (size_t)B * L;
+    hipLaunchKernelGGL(tg_chunk_sums, dim3(B * chunks), dim3(256), 0, st, L, chunks, deg, sums);
+    hipLaunchKernelGGL(tg_scan_sums, dim3(B), dim3(256), 0, st, chunks, M * K, sums);
+    hipLaunchKernelGGL(tg_apply, dim3(B * chunks), dim3(256), 0, st, L, chunks, deg, sums, offsets);
     if (total > 0)
         hipLaunchKernelGGL(tg_fill, dim3((unsigned)blocks), dim3(256), 0, st, B, N, M, K, F, nn_index, nn_count, bin_index,
                            weight, offsets, deg, ent_key, ent_scale);

@@ -70,38 +70,119 @@ def _separable_conv3d_block(net, list_channels, bin_size, nn_index, nn_count, fi
     return net
 
 
-def build_graphs(points, config):
-    """All graph-construction ops of one forward (they depend on xyz only): returns the
-    encoder and decoder graph lists.  Separated so the bench can time / overlap it explicitly."""
-    xyz = points[:, :, 0:3]
-    enc = []
-    xyz_layers = [xyz]
+_side_stream = {}
+
+
+class GraphPlan:
+    """All graph-construction ops of one forward (they depend on xyz only), built lazily level by
+    level.  Same ops, arguments and results as the build_graph / build_graph_deconv / spherical_kernel calls of
+    models/SPH3D_s3dis.py:53-98; only the ISSUE ORDER differs: FPS is m strictly sequential rounds on one
+    workgroup per cloud (16 of 256 CUs busy), so on the GPU the whole sampling chain is launched up front on a
+    side HIP stream and overlaps the level-0 neighbour search, kernel binning and convolutions, which need only
+    the input xyz; the main stream waits (per level) only where sampled coordinates are first needed."""
+
+    def __init__(self, points, config, overlap=True):
+        self.config = config
+        xyz = points[:, :, 0:3]
+        self.use_side = bool(overlap and xyz.is_cuda)
+        self.xyz_layers, self.indices, self.events = [xyz], [], []
+        self._enc, self._dec = {}, {}
+        if self.use_side:
+            self.main = torch.cuda.current_stream()
+            side = _side_stream.get(xyz.device)
+            if side is None:
+                side = _side_stream[xyz.device] = torch.cuda.Stream(device=xyz.device)
+            side.wait_stream(self.main)
+            with torch.cuda.stream(side):
+                self._sampling_chain(side)
+        else:
+            self._sampling_chain(None)
+        self._waited = 0          # number of sampling levels the main stream has synchronised with
+
+    def _sampling_chain(self, side):
+        """FPS level after level (each level samples the previous level's samples)."""
+        config = self.config
+        for l in range(len(config.radius)):
+            if config.num_sample[l] > 1:
+                cur = self.xyz_layers[-1]
+                if config.sample == 'FPS':
+                    sample_index = s3g_util.farthest_point_sample(config.num_sample[l], cur)
+                elif config.sample == 'random':
+                    sample_index = s3g_util.random_sample(config.num_sample[l], cur)
+                else:
+                    raise ValueError('Unknown sampling method.')
+                B = cur.shape[0]
+                batch_indices = torch.arange(B, dtype=torch.int32, device=cur.device).view(-1, 1, 1)
+                indices = torch.cat([batch_indices.expand(B, config.num_sample[l], 1),
+                                     sample_index.unsqueeze(2).to(torch.int32)], dim=2)      # util.py:43-45
+                self.indices.append(indices)
+                self.xyz_layers.append(s3g_util.gather_nd(cur, indices))
+            else:
+                self.indices.append(None)
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record(side)
+                self.events.append(ev)
+
+    def _need_sampling(self, levels):
+        """main stream may use the results of sampling levels < `levels`"""
+        if not self.use_side:
+            return
+        while self._waited < levels:
+            l = self._waited
+            self.main.wait_event(self.events[l])
+            if self.indices[l] is not None:
+                self.indices[l].record_stream(self.main)
+                self.xyz_layers[l + 1].record_stream(self.main)
+            self._waited += 1
+
+    def enc(self, l):
+        """encoder level l: intra graph + bins of xyz_l (needs sampling levels < l)"""
+        if l not in self._enc:
+            c = self.config
+            self._need_sampling(l)
+            xyz = self.xyz_layers[l]
+            idx, cnt, dst = s3g_util.neighbor_fn(xyz, xyz, radius=c.radius[l], nnsample=c.nn_uplimit[l])  # util.py:29
+            filt = s3g_util.spherical_kernel(xyz, xyz, idx, cnt, dst, c.radius[l], kernel=c.kernel)
+            self._enc[l] = dict(intra_idx=idx, intra_cnt=cnt, filt_idx=filt)
+        return self._enc[l]
+
+    def pool(self, l):
+        """rows of the level-l intra graph at the sampled points (models/SPH3D_s3dis.py:68-72)"""
+        g = self.enc(l)
+        if "inter_idx" not in g:
+            self._need_sampling(l + 1)
+            g["inter_idx"] = s3g_util.gather_nd(g["intra_idx"], self.indices[l])
+            g["inter_cnt"] = s3g_util.gather_nd(g["intra_cnt"], self.indices[l])
+        return g
+
+    def dec(self, l):
+        if l not in self._dec:
+            c = self.config
+            L = len(c.radius)
+            self._need_sampling(L)
+            radius, uplimit = c.radius[L - 1 - l], c.nn_uplimit[L - 1 - l]
+            xyz_rev = list(reversed(self.xyz_layers))
+            xyz_c, xyz_unpool = xyz_rev[l], xyz_rev[l + 1]
+            intra_idx, intra_cnt, intra_dst, inter_idx, inter_cnt, inter_dst = s3g_util.build_graph_deconv(
+                xyz_c, xyz_unpool, radius, uplimit)
+            filt_idx = s3g_util.spherical_kernel(xyz_c, xyz_c, intra_idx, intra_cnt, intra_dst, radius,
+                                                 kernel=c.kernel)
+            self._dec[l] = dict(intra_idx=intra_idx, intra_cnt=intra_cnt, filt_idx=filt_idx, inter_idx=inter_idx,
+                                inter_cnt=inter_cnt, inter_dst=inter_dst)
+        return self._dec[l]
+
+
+def build_graphs(points, config, overlap=True):
+    """Eagerly build every graph of one forward -> GraphPlan (kept for tests / smoke that inspect the graphs)."""
+    plan = GraphPlan(points, config, overlap=overlap)
     for l in range(len(config.radius)):
-        intra_idx, intra_cnt, intra_dst, indices = s3g_util.build_graph(
-            xyz, config.radius[l], config.nn_uplimit[l], config.num_sample[l], sample_method=config.sample)
-        filt_idx = s3g_util.spherical_kernel(xyz, xyz, intra_idx, intra_cnt, intra_dst, config.radius[l],
-                                             kernel=config.kernel)
-        g = dict(intra_idx=intra_idx, intra_cnt=intra_cnt, filt_idx=filt_idx)
+        plan.enc(l)
         if config.num_sample[l] > 1:
-            xyz = s3g_util.gather_nd(xyz, indices)
-            xyz_layers.append(xyz)
-            g["inter_idx"] = s3g_util.gather_nd(intra_idx, indices)
-            g["inter_cnt"] = s3g_util.gather_nd(intra_cnt, indices)
-        enc.append(g)
-    radius = list(reversed(config.radius))
-    nn_uplimit = list(reversed(config.nn_uplimit))
-    xyz_rev = list(reversed(xyz_layers))
-    dec = []
-    for l in range(len(radius)):
-        xyz = xyz_rev[l]
-        xyz_unpool = xyz_rev[l + 1]
-        intra_idx, intra_cnt, intra_dst, inter_idx, inter_cnt, inter_dst = s3g_util.build_graph_deconv(
-            xyz, xyz_unpool, radius[l], nn_uplimit[l])
-        filt_idx = s3g_util.spherical_kernel(xyz, xyz, intra_idx, intra_cnt, intra_dst, radius[l],
-                                             kernel=config.kernel)
-        dec.append(dict(intra_idx=intra_idx, intra_cnt=intra_cnt, filt_idx=filt_idx, inter_idx=inter_idx,
-                        inter_cnt=inter_cnt, inter_dst=inter_dst))
-    return enc, dec
+            plan.pool(l)
+    for l in range(len(config.radius)):
+        plan.dec(l)
+    return plan
 
 
 def get_model(points, is_training, config=None, graphs=None):
@@ -114,25 +195,24 @@ def get_model(points, is_training, config=None, graphs=None):
     net = s3g_util.pointwise_conv3d(net, config.mlp, 'mlp1', weight_decay=config.weight_decay,
                                     with_bn=config.with_bn, with_bias=config.with_bias, reuse=reuse,
                                     is_training=is_training)
-    if graphs is None:
-        graphs = build_graphs(points, config)
-    enc, dec = graphs
+    plan = graphs if graphs is not None else GraphPlan(points, config)
     encoder = []
     for l in range(len(config.radius)):
-        g = enc[l]
+        g = plan.enc(l)
         net = _separable_conv3d_block(net, config.channels[l], config.binSize, g["intra_idx"], g["intra_cnt"],
                                       g["filt_idx"], 'conv' + str(l + 1), config.multiplier[l], reuse=reuse,
                                       weight_decay=config.weight_decay, with_bn=config.with_bn,
                                       with_bias=config.with_bias, is_training=is_training)
         encoder.append(net)
         if config.num_sample[l] > 1:
+            g = plan.pool(l)
             net = s3g_util.pool3d(net, g["inter_idx"], g["inter_cnt"], method=config.pool_method,
                                   scope='pool' + str(l + 1))
     channels = list(reversed(config.channels))
     multiplier = list(reversed(config.multiplier))
     encoder.reverse()
     for l in range(len(channels)):
-        g = dec[l]
+        g = plan.dec(l)
         net = _separable_conv3d_block(net, channels[l], config.binSize, g["intra_idx"], g["intra_cnt"],
                                       g["filt_idx"], 'deconv' + str(l + 1), multiplier[l], reuse=reuse,
                                       weight_decay=config.weight_decay, with_bn=config.with_bn,
