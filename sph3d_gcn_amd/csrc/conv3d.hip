@@ -6,9 +6,10 @@
 // MI355X design:
 //   * One WAVEFRONT per output point (the reference: one thread per output CHANNEL, every
 //     channel-thread re-reading the neighbour/bin lists and doing K read-modify-writes on global
-//     memory).  The point's neighbour ids and bin ids are read through the scalar cache (the row address is wave-uniform)
-//     with s_load, so the inner loop's gather addresses
-//     are scalar and every gathered feature row is one coalesced wave read (float2/float4 per lane).
+//     memory).  The point's neighbour ids and bin ids are fetched ONCE as two coalesced 256-B reads (lane k
+//     holds slot k) and broadcast lane->scalar with v_readlane eight at a time, so eight gather addresses are
+//     scalar, eight feature-row gathers (each one coalesced wave read, float2/float4 per lane) and eight LDS
+//     filter reads are in flight before the first FMA.
 //   * Lanes span output channels, 4 consecutive channels per lane: accumulate in registers, one
 //     coalesced float4 store per point.  A "slice" is 256 output channels; wider layers loop slices.
 //   * The filter table slice (F x 256 floats = 33 KB at F=33) lives in LDS, read as ds_read_b128.
@@ -27,6 +28,7 @@ namespace sph3d {
 
 constexpr int kSlice = 256;       // output channels per wave pass (64 lanes x 4)
 constexpr int kFwdPointsPerWG = 32;
+constexpr int kBatch = 8;        // neighbours whose gathers are issued together
 
 // ------------------------------------------------------------------------------------------
 // forward, vectorised: R = depth multiplier (1 or 2), CR % 4 == 0
@@ -35,7 +37,8 @@ template <int R>
 __global__ __launch_bounds__(256) void dwconv_fwd_vec(
     int B, int N, int M, int F, int C, int K, int mblocks, int nslices,
     const int* __restrict__ nnIndex, const int* __restrict__ nnCount, const int* __restrict__ binIndex,
-    const float* __restrict__ input, const float* __restrict__ filter, float* __restrict__ output)
+    const float* __restrict__ input, const float* __restrict__ filter, float* __restrict__ output,
+    const int* __restrict__ order)
 {
     extern __shared__ __attribute__((aligned(16))) float lfilt[];   // [F][SL]
     const int CR = C * R;
@@ -60,35 +63,55 @@ __global__ __launch_bounds__(256) void dwconv_fwd_vec(
     const int cl0 = lane * 4;
     const bool act = cl0 < SL;
     const int cin0 = (slice0 + cl0) / R;      // first input channel of this lane
+    const int clc = act ? cl0 : 0;            // clamped copies for branch-free loads
+    const int cinc = act ? cin0 : slice0 / R;
+    (void)cin0;
     const int m_begin = mb * kFwdPointsPerWG;
     const int m_end = (m_begin + kFwdPointsPerWG) < M ? (m_begin + kFwdPointsPerWG) : M;
     const float* inb = input + (size_t)b * N * C;
 
-    for (int m = m_begin + wave; m < m_end; m += 4) {
+    for (int mi = m_begin + wave; mi < m_end; mi += 4) {
+        const int m = order ? uniform(order[(size_t)b * M + mi]) : mi;    // optional processing order
         const size_t row = (size_t)b * M + m;
         const int cnt = uniform(nnCount[row]);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int* __restrict__ irow = nnIndex + row * K;   // wave-uniform address -> scalar loads
-        const int* __restrict__ brow = binIndex + row * K;
-        {
-#pragma unroll 4
-            for (int kk = 0; kk < cnt; kk++) {
-                const int n = irow[kk];
-                const int f = brow[kk];
-                if (act) {
-                    const float4 w = *reinterpret_cast<const float4*>(&lfilt[f * SL + cl0]);
+        for (int kt = 0; kt < cnt; kt += 64) {
+            // the row's neighbour ids and bin ids: ONE coalesced 256-B read each (lane k holds slot kt + k) ...
+            const int myk = kt + lane;
+            const int idxv = myk < cnt ? nnIndex[row * K + myk] : 0;
+            const int binv = myk < cnt ? binIndex[row * K + myk] : 0;
+            const int kn = (cnt - kt) < 64 ? (cnt - kt) : 64;
+            // ... then consumed eight at a time: 8 lane->scalar broadcasts, 8 independent row gathers and 8 filter
+            // reads are in flight before the first FMA (the kernel is latency-bound otherwise)
+            for (int k8 = 0; k8 < kn; k8 += kBatch) {
+                int n[kBatch], f[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; u++) {
+                    const int kk = (k8 + u) < kn ? (k8 + u) : (kn - 1);
+                    n[u] = __builtin_amdgcn_readlane(idxv, kk);
+                    f[u] = __builtin_amdgcn_readlane(binv, kk);
+                }
+                float4 w[kBatch];
+                float4 x[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; u++) {
+                    // no per-lane branch here: inactive lanes (slices narrower than 256) read lane 0's columns, so the
+                    // eight loads stay in one basic block and are all in flight together
+                    w[u] = *reinterpret_cast<const float4*>(&lfilt[f[u] * SL + clc]);
                     if (R == 2) {
-                        const float2 x = *reinterpret_cast<const float2*>(&inb[(size_t)n * C + cin0]);
-                        acc.x = fmaf(x.x, w.x, acc.x);
-                        acc.y = fmaf(x.x, w.y, acc.y);
-                        acc.z = fmaf(x.y, w.z, acc.z);
-                        acc.w = fmaf(x.y, w.w, acc.w);
+                        const float2 t = *reinterpret_cast<const float2*>(&inb[(size_t)n[u] * C + cinc]);
+                        x[u] = make_float4(t.x, t.x, t.y, t.y);
                     } else {
-                        const float4 x = *reinterpret_cast<const float4*>(&inb[(size_t)n * C + cin0]);
-                        acc.x = fmaf(x.x, w.x, acc.x);
-                        acc.y = fmaf(x.y, w.y, acc.y);
-                        acc.z = fmaf(x.z, w.z, acc.z);
-                        acc.w = fmaf(x.w, w.w, acc.w);
+                        x[u] = *reinterpret_cast<const float4*>(&inb[(size_t)n[u] * C + cinc]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kBatch; u++) {
+                    if ((k8 + u) < kn) {      // wave-uniform: padding slots of the last batch are skipped
+                        acc.x = fmaf(x[u].x, w[u].x, acc.x);
+                        acc.y = fmaf(x[u].y, w[u].y, acc.y);
+                        acc.z = fmaf(x[u].z, w[u].z, acc.z);
+                        acc.w = fmaf(x[u].w, w[u].w, acc.w);
                     }
                 }
             }
@@ -230,7 +253,7 @@ __global__ __launch_bounds__(kBwdTWaves * 64) void dwconv_bwd_t_vec(
     const int cin0 = (slice0 + cl0) / R;
     const int n_begin = nb * kBwdTPointsPerWG;
     const int n_end = (n_begin + kBwdTPointsPerWG) < N ? (n_begin + kBwdTPointsPerWG) : N;
-    const float* gob = gradOutput + (size_t)b * M * CR + slice0 + cl0;
+    const float* gob = gradOutput + (size_t)b * M * CR + slice0 + (act ? cl0 : 0);
     const int* __restrict__ offb = offsets + (size_t)b * ((size_t)N * F + 1);
 
     // per-lane gradient-of-filter accumulators, one row per bin; every index below is a compile-time constant
@@ -245,7 +268,7 @@ __global__ __launch_bounds__(kBwdTWaves * 64) void dwconv_bwd_t_vec(
         const int* __restrict__ o = offb + (size_t)n * F;      // F+1 consecutive segment bounds: scalar loads
         float xi[VI], xv[V];
 #pragma unroll
-        for (int u = 0; u < VI; u++) xi[u] = act ? input[((size_t)b * N + n) * C + cin0 + u] : 0.f;
+        for (int u = 0; u < VI; u++) xi[u] = input[((size_t)b * N + n) * C + (act ? cin0 : slice0 / R) + u];
 #pragma unroll
         for (int v = 0; v < V; v++) xv[v] = xi[(V >= R) ? v / R : 0];
         float gi[V];
@@ -272,18 +295,15 @@ __global__ __launch_bounds__(kBwdTWaves * 64) void dwconv_bwd_t_vec(
                         float g[4][V];
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
-#pragma unroll
-                            for (int v = 0; v < V; v++) g[u][v] = 0.f;
-                            if (act) {
-                                if (V == 4) {
-                                    const float4 t = *reinterpret_cast<const float4*>(&gob[(size_t)mm[u] * CR]);
-                                    g[u][0] = t.x; g[u][1 % V] = t.y; g[u][2 % V] = t.z; g[u][3 % V] = t.w;
-                                } else if (V == 2) {
-                                    const float2 t = *reinterpret_cast<const float2*>(&gob[(size_t)mm[u] * CR]);
-                                    g[u][0] = t.x; g[u][1 % V] = t.y;
-                                } else {
-                                    g[u][0] = gob[(size_t)mm[u] * CR];
-                                }
+                            // branch-free (inactive lanes read lane 0's columns): the four gathers stay in one basic block
+                            if (V == 4) {
+                                const float4 t = *reinterpret_cast<const float4*>(&gob[(size_t)mm[u] * CR]);
+                                g[u][0] = t.x; g[u][1 % V] = t.y; g[u][2 % V] = t.z; g[u][3 % V] = t.w;
+                            } else if (V == 2) {
+                                const float2 t = *reinterpret_cast<const float2*>(&gob[(size_t)mm[u] * CR]);
+                                g[u][0] = t.x; g[u][1 % V] = t.y;
+                            } else {
+                                g[u][0] = gob[(size_t)mm[u] * CR];
                             }
                         }
 #pragma unroll
@@ -429,6 +449,9 @@ static int conv_dims_ok(int B, int N, int M, int F, int C, int r, int K, const c
 
 using namespace sph3d;
 
+static const int* g_order = nullptr;
+extern "C" void sph3d_debug_order(const int* o) { g_order = o; }
+
 extern "C" int sph3d_depthwise_conv3d(int B, int N, int M, int F, int C, int r, int K,
                                       const int* nn_index, const int* nn_count, const int* bin_index,
                                       const float* input, const float* filter, float* output,
@@ -454,11 +477,11 @@ extern "C" int sph3d_depthwise_conv3d(int B, int N, int M, int F, int C, int r, 
     if (vec && r == 2) {
         SPH3D_BIG_LDS(dwconv_fwd_vec<2>)
         hipLaunchKernelGGL(dwconv_fwd_vec<2>, grid, dim3(256), lds, st, B, N, M, F, C, K, mblocks, nslices,
-                           nn_index, nn_count, bin_index, input, filter, output);
+                           nn_index, nn_count, bin_index, input, filter, output, g_order);
     } else if (vec) {
         SPH3D_BIG_LDS(dwconv_fwd_vec<1>)
         hipLaunchKernelGGL(dwconv_fwd_vec<1>, grid, dim3(256), lds, st, B, N, M, F, C, K, mblocks, nslices,
-                           nn_index, nn_count, bin_index, input, filter, output);
+                           nn_index, nn_count, bin_index, input, filter, output, g_order);
     } else {
         SPH3D_BIG_LDS(dwconv_fwd_generic)
         hipLaunchKernelGGL(dwconv_fwd_generic, grid, dim3(256), lds, st, B, N, M, F, C, r, K, mblocks, nslices,

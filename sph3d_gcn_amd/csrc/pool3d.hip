@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void gather_fwd(
         for (int c0 = 0; c0 < C; c0 += 64 * V) {
             const int c = c0 + lane * V;
             const bool act = c < C;
+            const int cc = act ? c : 0;
             float acc[V];
             int arg[V];
 #pragma unroll
@@ -50,18 +51,18 @@ __global__ __launch_bounds__(256) void gather_fwd(
             const int* __restrict__ irow = nnIndex + row * K;   // wave-uniform address -> scalar loads
             const float* __restrict__ wrow = weight + row * K;
             {
-#pragma unroll 4
+#pragma unroll 8
                 for (int kk = 0; kk < cnt; kk++) {
                     const int n = irow[kk];
                     float w = 1.f;
                     if (MODE == Mode::Weighted) w = wrow[kk];
-                    if (act) {
-                        float x[V];
+                    {
+                        float x[V];          // branch-free: inactive lanes read channel 0 (keeps the unrolled gathers in flight)
                         if (V == 4) {
-                            const float4 t = *reinterpret_cast<const float4*>(&inb[(size_t)n * C + c]);
+                            const float4 t = *reinterpret_cast<const float4*>(&inb[(size_t)n * C + cc]);
                             x[0] = t.x; x[1 % V] = t.y; x[2 % V] = t.z; x[3 % V] = t.w;
                         } else {
-                            x[0] = inb[(size_t)n * C + c];
+                            x[0] = inb[(size_t)n * C + cc];
                         }
 #pragma unroll
                         for (int v = 0; v < V; v++) {
@@ -115,22 +116,23 @@ __global__ __launch_bounds__(256) void gather_bwd_t(
         for (int c0 = 0; c0 < C; c0 += 64 * V) {
             const int c = c0 + lane * V;
             const bool act = c < C;
+            const int cc = act ? c : 0;
             float acc[V];
 #pragma unroll
             for (int v = 0; v < V; v++) acc[v] = 0.f;
-#pragma unroll 4
+#pragma unroll 8
             for (int e = e0; e < e1; e++) {
                 const int m = entKey[e];
                 const float sc = entScale[e];
-                if (act) {
+                {   // branch-free: inactive lanes read channel 0
                     if (V == 4) {
-                        const float4 t = *reinterpret_cast<const float4*>(&gob[(size_t)m * C + c]);
+                        const float4 t = *reinterpret_cast<const float4*>(&gob[(size_t)m * C + cc]);
                         acc[0] = fmaf(t.x, sc, acc[0]);
                         acc[1 % V] = fmaf(t.y, sc, acc[1 % V]);
                         acc[2 % V] = fmaf(t.z, sc, acc[2 % V]);
                         acc[3 % V] = fmaf(t.w, sc, acc[3 % V]);
                     } else {
-                        acc[0] = fmaf(gob[(size_t)m * C + c], sc, acc[0]);
+                        acc[0] = fmaf(gob[(size_t)m * C + cc], sc, acc[0]);
                     }
                 }
             }
