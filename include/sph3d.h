@@ -198,6 +198,24 @@ int sph3d_farthest_point_sample(int b, int n, int m, const float* inp, int* out,
                                 void* workspace, size_t workspace_bytes,
                                 sph3d_stream_t stream);
 
+/* ---- pointwise 1x1 feature GEMM (fp32 MFMA) -----------------------------
+ * replaces the tf.matmul inside separable_conv3d / pointwise_conv3d /
+ * fully_connected (utils/sph3gcn_util.py:146-150, 204-206, 260) -> cuBLAS SGEMM
+ * in the reference.  Y[R,Cout] = X[R,Cin] * W[Cin,Cout] (+ bias[Cout]) with an
+ * optional fused ELU; exact fp32 (v_mfma_f32_32x32x2_f32).
+ * act: 0 = none, 1 = ELU.  bias may be NULL.
+ * trans_x / trans_w select the backward products:
+ *   dX[R,Cin]  = dY[R,Cout] * W^T      -> sph3d_pointwise_gemm(R, Cout, Cin, dY, W, trans_w=1)
+ *   dW[Cin,Cout] = X^T[Cin,R] * dY     -> sph3d_pointwise_gemm_tn(...) */
+int sph3d_pointwise_gemm(int R, int Cin, int Cout,
+                         const float* X, const float* W, const float* bias, int act,
+                         int trans_w, float* Y, sph3d_stream_t stream);
+int sph3d_pointwise_gemm_tn(int R, int Cin, int Cout,
+                            const float* X, const float* dY, float* dW,
+                            void* workspace, size_t workspace_bytes,
+                            sph3d_stream_t stream);
+size_t sph3d_pointwise_gemm_tn_workspace(int R, int Cin, int Cout);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,328 @@
+// gemm.hip — pointwise 1x1 feature GEMM on the fp32 matrix cores of gfx950.
+//
+// Replaces the tf.matmul inside separable_conv3d / pointwise_conv3d / fully_connected
+// (utils/sph3gcn_util.py:146-150, 204-206, 260; cuBLAS SGEMM in the reference) and its two backward products.
+//
+// All three products are tall-skinny: R = B*points rows (up to 131072), channel dims 3..2048.
+//   NN : Y [R,Cout]   = X [R,Cin]  * W[Cin,Cout]   (+bias, optional ELU)          forward
+//   NT : dX[R,Cin]    = dY[R,Cout] * W^T                                           input gradient
+//   TN : dW[Cin,Cout] = X^T        * dY[R,Cout]     (reduction over R, split-K)    weight gradient
+//
+// MI355X design: v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain, no TF32-style truncation, so the
+// 1e-5 activation bound holds).  Workgroup = 4 waves, block tile 128x128 / 128x64 / 64x64 (the largest that still
+// gives all 256 CUs work: the row count shrinks 64-fold from level 0 to level 3), BK = 16; each wave owns a quarter
+// of the tile as independent 32x32 accumulators.  Operand tiles go global -> registers (prefetch of tile t+1 during
+// the MFMAs of tile t) -> a double-buffered LDS image lds[row][k] (one barrier per k-tile) from which a lane's
+// operands for four MFMA steps are a single conflict-free ds_read_b128 (Stage / kmap comments below).
+// Ragged edges (Cin = 3, Cout = 13, R not a multiple of 128) take guarded scalar loads / stores.
+// TN splits R over workgroups; every split writes its partial tile to a workspace slab and a second kernel adds the
+// slabs in a fixed order (deterministic, no float atomics).
+#include "common.hpp"
+
+namespace sph3d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;
+constexpr int BK = 16;
+
+// load a 4-wide chunk of a [rows x cols] row-major matrix at (r, c..c+3), zero outside
+__device__ __forceinline__ float4 load4_guard(const float* __restrict__ p, int ld, int r, int c, int rows, int cols, bool vec_ok)
+{
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) {
+        const float* q = p + (size_t)r * ld + c;
+        if (vec_ok && c + 3 < cols) {
+            v = *reinterpret_cast<const float4*>(q);
+        } else {
+            if (c < cols) v.x = q[0];
+            if (c + 1 < cols) v.y = q[1];
+            if (c + 2 < cols) v.z = q[2];
+            if (c + 3 < cols) v.w = q[3];
+        }
+    }
+    return v;
+}
+
+// Operand tile staging.  Whatever the memory order, the LDS image is lds[row][k] with row stride BK+4 floats:
+//   * a lane's MFMA fragment for FOUR consecutive k-steps is one aligned ds_read_b128 (see kmap below);
+//   * 16 rows x stride 20 dwords hit 16 distinct 4-dword bank slots -> the b128 reads are conflict-free;
+//   * KMAJ sources (k contiguous in memory) store with ds_write_b128, the others with 4 scalar stores.
+// KMAJ = true : memory is [row][k] (k contiguous);  KMAJ = false: memory is [k][row] (row contiguous).
+// BT = tile extent along the row dimension.  256 threads.
+constexpr int LDK = BK + 4;
+
+template <bool KMAJ, int BT>
+struct Stage {
+    static constexpr int NCH = (BT * BK / 4 + 255) / 256;        // float4 chunks per thread
+    static constexpr int LDS_FLOATS = BT * LDK;
+    float4 r[NCH];
+
+    // GUARD = false (every tile fully inside both matrices, 16-B aligned rows — chosen on the host): the loads carry no
+    // branch at all, stay in one basic block and are in flight during the MFMAs of the current tile.  (A run-time
+    // uniform `fast` flag was not enough: with the guarded path in the same kernel hipcc drained vmcnt before the MFMAs.)
+    template <bool GUARD>
+    __device__ __forceinline__ void load(const float* __restrict__ p, int ld, int row0, int k0, int rows, int kdim, bool vec_ok)
+    {
+        if (!GUARD) {
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                const int ch = (int)threadIdx.x + i * 256;
+                if (BT * BK / 4 < 256 && ch >= BT * BK / 4) { r[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+                if (KMAJ) {
+                    const int row = ch / (BK / 4), kq = ch % (BK / 4);
+                    r[i] = *reinterpret_cast<const float4*>(p + (size_t)(row0 + row) * ld + k0 + kq * 4);
+                } else {
+                    const int k = ch / (BT / 4), rq = ch % (BT / 4);
+                    r[i] = *reinterpret_cast<const float4*>(p + (size_t)(k0 + k) * ld + row0 + rq * 4);
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int ch = (int)threadIdx.x + i * 256;
+            if (BT * BK / 4 < 256 && ch >= BT * BK / 4) { r[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+            if (KMAJ) {
+                const int row = ch / (BK / 4), kq = ch % (BK / 4);
+                r[i] = load4_guard(p, ld, row0 + row, k0 + kq * 4, rows, kdim, vec_ok);
+            } else {
+                const int k = ch / (BT / 4), rq = ch % (BT / 4);
+                r[i] = load4_guard(p, ld, k0 + k, row0 + rq * 4, kdim, rows, vec_ok);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* lds) const
+    {
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int ch = (int)threadIdx.x + i * 256;
+            if (BT * BK / 4 < 256 && ch >= BT * BK / 4) continue;
+            if (KMAJ) {
+                const int row = ch / (BK / 4), kq = ch % (BK / 4);
+                *reinterpret_cast<float4*>(lds + row * LDK + kq * 4) = r[i];
+            } else {
+                const int k = ch / (BT / 4), rq = ch % (BT / 4);
+                float* d = lds + (rq * 4) * LDK + k;
+                d[0] = r[i].x; d[LDK] = r[i].y; d[2 * LDK] = r[i].z; d[3 * LDK] = r[i].w;
+            }
+        }
+    }
+};
+
+// k assignment inside a group of 8 consecutive k: MFMA step s (0..3) multiplies k = 8g + s (lanes 0..31) with
+// k = 8g + 4 + s (lanes 32..63).  Any pairing is legal (the sum over k is what matters, A and B use the same one);
+// this one makes a lane's operands for the 4 steps of a group ONE float4 at lds[row][8g + 4*(lane>>5)].
+//
+// C[M,N] = A * B for one BMT x BN tile and the k range [k_begin, k_end).
+// A(m,k): AK ? A[m*lda + k] : A[k*lda + m].   B(k,n): BKM ? B[n*ldb + k] : B[k*ldb + n].
+template <bool AK, bool BKM, int BMT, int BN, bool SPLITK, bool GUARD>
+__global__ __launch_bounds__(256) void gemm_f32_mfma(int M, int N, int Kd, const float* __restrict__ A, int lda,
+                                                     const float* __restrict__ B, int ldb, float* __restrict__ Cmat,
+                                                     int ldc, const float* __restrict__ bias, int act, int kchunk)
+{
+    using SA = Stage<AK, BMT>;
+    using SB = Stage<BKM, BN>;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (SA::LDS_FLOATS + SB::LDS_FLOATS)];
+    constexpr int WM = BMT / 2, WN = BN / 2;     // wave sub-tile
+    constexpr int TM = WM / 32, TN = WN / 32;    // MFMA tiles per wave
+
+    const int tiles_n = (N + BN - 1) / BN;
+    const int tile = (int)blockIdx.x;
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    const int m0 = tm * BMT, n0 = tn * BN;
+    const int k_begin = SPLITK ? (int)blockIdx.y * kchunk : 0;
+    const int k_end = SPLITK ? ((k_begin + kchunk) < Kd ? (k_begin + kchunk) : Kd) : Kd;
+
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+    const int li = lane & 31, lk = lane >> 5;
+
+    const bool a_vec = (lda % 4 == 0) && ((reinterpret_cast<size_t>(A) & 15) == 0);
+    const bool b_vec = (ldb % 4 == 0) && ((reinterpret_cast<size_t>(B) & 15) == 0);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    SA sa;
+    SB sb;
+    constexpr int BUF = SA::LDS_FLOATS + SB::LDS_FLOATS;     // buffer b: A image at lds + b*BUF, B image after it
+    sa.template load<GUARD>(A, lda, m0, k_begin, M, k_end, a_vec);
+    sb.template load<GUARD>(B, ldb, n0, k_begin, N, k_end, b_vec);
+    sa.store(lds);
+    sb.store(lds + SA::LDS_FLOATS);
+    __syncthreads();
+
+    int buf = 0;
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        const bool more = (k0 + BK) < k_end;
+        if (more) {                       // global -> registers for tile t+1 while tile t is multiplied
+            sa.template load<GUARD>(A, lda, m0, k0 + BK, M, k_end, a_vec);
+            sb.template load<GUARD>(B, ldb, n0, k0 + BK, N, k_end, b_vec);
+        }
+        const float* ca = lds + buf * BUF;
+        const float* cb = ca + SA::LDS_FLOATS;
+#pragma unroll
+        for (int g = 0; g < BK / 8; g++) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const float4*>(ca + (wm + i * 32 + li) * LDK + g * 8 + lk * 4);
+#pragma unroll
+            for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const float4*>(cb + (wn + j * 32 + li) * LDK + g * 8 + lk * 4);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) {
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) {
+                        const float av = s4 == 0 ? af[i].x : (s4 == 1 ? af[i].y : (s4 == 2 ? af[i].z : af[i].w));
+                        const float bv = s4 == 0 ? bf[j].x : (s4 == 1 ? bf[j].y : (s4 == 2 ? bf[j].z : bf[j].w));
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+        if (more) {                       // the other buffer: nobody reads it during this iteration
+            sa.store(lds + (buf ^ 1) * BUF);
+            sb.store(lds + (buf ^ 1) * BUF + SA::LDS_FLOATS);
+        }
+        __syncthreads();                  // ONE barrier per k-tile
+        buf ^= 1;
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+    float* Cout = SPLITK ? Cmat + (size_t)blockIdx.y * ((size_t)M * ldc) : Cmat;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int col = n0 + wn + j * 32 + li;
+            const float bv = (!SPLITK && bias != nullptr && col < N) ? bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                if (!GUARD || (row < M && col < N)) {
+                    float v = acc[i][j][e] + bv;
+                    if (!SPLITK && act == 1) v = v > 0.f ? v : expm1f(v);     // ELU (alpha = 1)
+                    Cout[(size_t)row * ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_reduce_splits(int nsplit, int total, const float* __restrict__ partial,
+                                                          float* __restrict__ out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total) return;
+    float s0 = 0.f, s1 = 0.f;
+    int p = 0;
+    for (; p + 2 <= nsplit; p += 2) {
+        s0 += partial[(size_t)p * total + j];
+        s1 += partial[(size_t)(p + 1) * total + j];
+    }
+    if (p < nsplit) s0 += partial[(size_t)p * total + j];
+    out[j] = s0 + s1;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+
+template <bool AK, bool BKM, bool GUARD>
+static void launch_gemm_tiles(int M, int N, int Kd, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                              const float* bias, int act, hipStream_t st)
+{
+    // tile choice: the largest tile that still gives every CU a workgroup
+    auto ntiles = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    if (N > 64 && ntiles(128, 128) >= 256) {
+        hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 128, false, GUARD>), dim3((unsigned)ntiles(128, 128)), dim3(256), 0, st,
+                           M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
+    } else if (ntiles(128, 64) >= 256) {
+        hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 64, false, GUARD>), dim3((unsigned)ntiles(128, 64)), dim3(256), 0, st,
+                           M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
+    } else {
+        hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 64, 64, false, GUARD>), dim3((unsigned)ntiles(64, 64)), dim3(256), 0, st, M,
+                           N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
+    }
+}
+
+template <bool AK, bool BKM>
+static int launch_gemm(int M, int N, int Kd, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                       const float* bias, int act, hipStream_t st)
+{
+    // unguarded kernels need whole tiles in every variant the tile chooser may pick (128 | M, 128 | N or 64 | N, 16 | K)
+    const bool whole = (M % 128 == 0) && (N % 64 == 0) && (N <= 64 || N % 128 == 0) && (Kd % BK == 0) &&
+                       (lda % 4 == 0) && (ldb % 4 == 0) && aligned16(A) && aligned16(B);
+    if (whole) launch_gemm_tiles<AK, BKM, false>(M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, st);
+    else launch_gemm_tiles<AK, BKM, true>(M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, st);
+    return check_launch("sph3d_pointwise_gemm");
+}
+
+// split-K plan for the weight gradient: enough (tile, split) workgroups to fill 256 CUs, k chunks multiple of BK
+static void tn_plan(int R, int Cin, int Cout, int& bn, int& tiles, int& nsplit, int& kchunk)
+{
+    bn = Cout > 64 ? 128 : 64;
+    tiles = ((Cin + BM - 1) / BM) * ((Cout + bn - 1) / bn);
+    int want = (1024 + tiles - 1) / tiles;            // ~4 workgroups per CU in total
+    int maxsplit = (R + 255) / 256;                   // at least 256 rows of k per split
+    nsplit = want < maxsplit ? want : maxsplit;
+    if (nsplit < 1) nsplit = 1;
+    kchunk = (R + nsplit - 1) / nsplit;
+    kchunk = ((kchunk + BK - 1) / BK) * BK;
+    nsplit = (R + kchunk - 1) / kchunk;
+}
+
+}  // namespace sph3d
+
+using namespace sph3d;
+
+extern "C" int sph3d_pointwise_gemm(int R, int Cin, int Cout, const float* X, const float* W, const float* bias, int act,
+                                    int trans_w, float* Y, sph3d_stream_t stream)
+{
+    SPH3D_REQUIRE(R >= 0 && Cin > 0 && Cout > 0, "pointwise_gemm: bad dims R=%d Cin=%d Cout=%d", R, Cin, Cout);
+    SPH3D_REQUIRE(act == 0 || act == 1, "pointwise_gemm: act must be 0 (none) or 1 (ELU), got %d", act);
+    if (R == 0) return SPH3D_OK;
+    hipStream_t st = as_stream(stream);
+    // Y[R,Cout] = X[R,Cin] * op(W);  trans_w: W is stored [Cout,Cin] (k contiguous), else [Cin,Cout] (n contiguous)
+    if (trans_w) return launch_gemm<true, true>(R, Cout, Cin, X, Cin, W, Cin, Y, Cout, bias, act, st);
+    return launch_gemm<true, false>(R, Cout, Cin, X, Cin, W, Cout, Y, Cout, bias, act, st);
+}
+
+extern "C" size_t sph3d_pointwise_gemm_tn_workspace(int R, int Cin, int Cout)
+{
+    int bn, tiles, nsplit, kchunk;
+    tn_plan(R, Cin, Cout, bn, tiles, nsplit, kchunk);
+    return nsplit > 1 ? sizeof(float) * (size_t)nsplit * Cin * Cout : 0;
+}
+
+extern "C" int sph3d_pointwise_gemm_tn(int R, int Cin, int Cout, const float* X, const float* dY, float* dW,
+                                       void* workspace, size_t workspace_bytes, sph3d_stream_t stream)
+{
+    SPH3D_REQUIRE(R > 0 && Cin > 0 && Cout > 0, "pointwise_gemm_tn: bad dims R=%d Cin=%d Cout=%d", R, Cin, Cout);
+    hipStream_t st = as_stream(stream);
+    int bn, tiles, nsplit, kchunk;
+    tn_plan(R, Cin, Cout, bn, tiles, nsplit, kchunk);
+    const size_t need = sph3d_pointwise_gemm_tn_workspace(R, Cin, Cout);
+    if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {
+        set_error("pointwise_gemm_tn: workspace %zu B < required %zu B", workspace_bytes, need);
+        return SPH3D_EWORKSPACE;
+    }
+    float* out = nsplit > 1 ? (float*)workspace : dW;
+    // dW[Cin,Cout] = X^T * dY : A(m=cin, k=r) = X[r*Cin + cin] (row contiguous), B(k=r, n=cout) = dY[r*Cout + cout]
+    const bool whole = (Cin % 128 == 0) && (Cout % bn == 0) && (R % kchunk == 0) && aligned16(X) && aligned16(dY);
+#define SPH3D_TN(BNN, G)                                                                                                   \
+    hipLaunchKernelGGL((gemm_f32_mfma<false, false, 128, BNN, true, G>), dim3(tiles, nsplit), dim3(256), 0, st, Cin, Cout, R, X, \
+                       Cin, dY, Cout, out, Cout, nullptr, 0, kchunk)
+    if (bn == 128) { if (whole) SPH3D_TN(128, false); else SPH3D_TN(128, true); }
+    else { if (whole) SPH3D_TN(64, false); else SPH3D_TN(64, true); }
+#undef SPH3D_TN
+    if (nsplit > 1) {
+        const int total = Cin * Cout;
+        hipLaunchKernelGGL(gemm_reduce_splits, dim3((total + 255) / 256), dim3(256), 0, st, nsplit, total, out, dW);
+    }
+    return check_launch("sph3d_pointwise_gemm_tn");
+}

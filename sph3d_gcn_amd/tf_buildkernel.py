@@ -7,8 +7,7 @@ import torch
 from . import _lib
 
 
-@torch.library.custom_op("sph3d::spherical_kernel", mutates_args=())
-def _spherical_kernel(database: torch.Tensor, query: torch.Tensor, nn_index: torch.Tensor,
+def _spherical_kernel_impl(database: torch.Tensor, query: torch.Tensor, nn_index: torch.Tensor,
                       nn_count: torch.Tensor, nn_dist: torch.Tensor, radius: float,
                       n_azim: int, p_elev: int, q_radi: int) -> torch.Tensor:
     _lib.require_device(database, query, nn_index, nn_count, nn_dist)
@@ -29,6 +28,9 @@ def _spherical_kernel(database: torch.Tensor, query: torch.Tensor, nn_index: tor
         B, N, M, K, n_azim, p_elev, q_radi, radius, _lib.ptr(database), _lib.ptr(query),
         _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(nn_dist), _lib.ptr(filt_index), _lib.stream_ptr()))
     return filt_index
+
+
+_spherical_kernel = torch.library.custom_op("sph3d::spherical_kernel", mutates_args=())(_spherical_kernel_impl)
 
 
 @_spherical_kernel.register_fake
@@ -52,4 +54,4 @@ def spherical_kernel(database, query, nn_index, nn_count, nn_dist, radius, kerne
     n, p, q = kernel
     database = database[:, :, 0:3]
     query = query[:, :, 0:3]
-    return _spherical_kernel(database, query, nn_index, nn_count, nn_dist, float(radius), int(n), int(p), int(q))
+    return _spherical_kernel_impl(database, query, nn_index, nn_count, nn_dist, float(radius), int(n), int(p), int(q))

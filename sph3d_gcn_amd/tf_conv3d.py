@@ -25,8 +25,7 @@ def _check_conv(input, filter, nn_index, nn_count, bin_index):
         raise ValueError("rank of nn_count should be 2")
 
 
-@torch.library.custom_op("sph3d::depthwise_conv3d", mutates_args=())
-def _depthwise_conv3d(input: torch.Tensor, filter: torch.Tensor, nn_index: torch.Tensor,
+def _depthwise_conv3d_impl(input: torch.Tensor, filter: torch.Tensor, nn_index: torch.Tensor,
                       nn_count: torch.Tensor, bin_index: torch.Tensor) -> torch.Tensor:
     _lib.require_device(input, filter, nn_index, nn_count, bin_index)
     _check_conv(input, filter, nn_index, nn_count, bin_index)
@@ -42,13 +41,15 @@ def _depthwise_conv3d(input: torch.Tensor, filter: torch.Tensor, nn_index: torch
     return output
 
 
+_depthwise_conv3d = torch.library.custom_op("sph3d::depthwise_conv3d", mutates_args=())(_depthwise_conv3d_impl)
+
+
 @_depthwise_conv3d.register_fake
 def _(input, filter, nn_index, nn_count, bin_index):
     return input.new_empty((input.shape[0], nn_index.shape[1], input.shape[2] * filter.shape[2]))
 
 
-@torch.library.custom_op("sph3d::depthwise_conv3d_grad", mutates_args=())
-def _depthwise_conv3d_grad(input: torch.Tensor, filter: torch.Tensor, grad_output: torch.Tensor,
+def _depthwise_conv3d_grad_impl(input: torch.Tensor, filter: torch.Tensor, grad_output: torch.Tensor,
                            nn_index: torch.Tensor, nn_count: torch.Tensor,
                            bin_index: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     _lib.require_device(input, filter, grad_output, nn_index, nn_count, bin_index)
@@ -72,6 +73,9 @@ def _depthwise_conv3d_grad(input: torch.Tensor, filter: torch.Tensor, grad_outpu
     return grad_input, grad_filter
 
 
+_depthwise_conv3d_grad = torch.library.custom_op("sph3d::depthwise_conv3d_grad", mutates_args=())(_depthwise_conv3d_grad_impl)
+
+
 @_depthwise_conv3d_grad.register_fake
 def _(input, filter, grad_output, nn_index, nn_count, bin_index):
     return torch.empty_like(input), torch.empty_like(filter)
@@ -91,6 +95,22 @@ def _conv_backward(ctx, grad_output):
 _depthwise_conv3d.register_autograd(_conv_backward, setup_context=_conv_setup)
 
 
+class _DepthwiseConv3dFn(torch.autograd.Function):
+    """Eager fast path of the public API: same implementation functions as the registered custom ops, without the
+    dispatcher round trip (the step issues ~230 op calls; the torch.library path costs ~4x more host time each)."""
+
+    @staticmethod
+    def forward(ctx, input, filter, nn_index, nn_count, bin_index):
+        ctx.save_for_backward(input, filter, nn_index, nn_count, bin_index)
+        return _depthwise_conv3d_impl(input, filter, nn_index, nn_count, bin_index)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, filter, nn_index, nn_count, bin_index = ctx.saved_tensors
+        gi, gf = _depthwise_conv3d_grad_impl(input, filter, grad_output, nn_index, nn_count, bin_index)
+        return gi, gf, None, None, None
+
+
 def depthwise_conv3d(input, filter, nn_index, nn_count, bin_index):
     '''
     Input:
@@ -102,8 +122,8 @@ def depthwise_conv3d(input, filter, nn_index, nn_count, bin_index):
     Output:
         output: (batch, mpoint, out_channels) float32 array, output point features
     '''
-    return _depthwise_conv3d(input, filter, nn_index, nn_count, bin_index)
+    return _DepthwiseConv3dFn.apply(input, filter, nn_index, nn_count, bin_index)
 
 
 def depthwise_conv3d_grad(input, filter, grad_output, nn_index, nn_count, bin_index):
-    return _depthwise_conv3d_grad(input, filter, grad_output, nn_index, nn_count, bin_index)
+    return _depthwise_conv3d_grad_impl(input, filter, grad_output, nn_index, nn_count, bin_index)

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 
-_backend = os.environ.get("SPH3D_GEMM", "blas")
+_backend = os.environ.get("SPH3D_GEMM", "hip")
 
 
 def set_backend(name):
@@ -31,8 +31,7 @@ def _have_hip_gemm():
     return hasattr(_lib.lib(), "sph3d_pointwise_gemm")
 
 
-@torch.library.custom_op("sph3d::pointwise_gemm", mutates_args=())
-def _pointwise_gemm(x: torch.Tensor, w: torch.Tensor, trans_w: bool) -> torch.Tensor:
+def _pointwise_gemm_impl(x: torch.Tensor, w: torch.Tensor, trans_w: bool) -> torch.Tensor:
     """y[R,Cout] = x[R,Cin] @ w[Cin,Cout]   (trans_w: w is stored [Cout,Cin])"""
     _lib.require_device(x, w)
     x, w = _lib.f32(x), _lib.f32(w)
@@ -44,13 +43,15 @@ def _pointwise_gemm(x: torch.Tensor, w: torch.Tensor, trans_w: bool) -> torch.Te
     return y
 
 
+_pointwise_gemm = torch.library.custom_op("sph3d::pointwise_gemm", mutates_args=())(_pointwise_gemm_impl)
+
+
 @_pointwise_gemm.register_fake
 def _(x, w, trans_w):
     return x.new_empty((x.shape[0], w.shape[0] if trans_w else w.shape[1]))
 
 
-@torch.library.custom_op("sph3d::pointwise_gemm_tn", mutates_args=())
-def _pointwise_gemm_tn(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+def _pointwise_gemm_tn_impl(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     """dw[Cin,Cout] = x[R,Cin]^T @ dy[R,Cout]"""
     _lib.require_device(x, dy)
     x, dy = _lib.f32(x), _lib.f32(dy)
@@ -63,6 +64,9 @@ def _pointwise_gemm_tn(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     _lib.check(l.sph3d_pointwise_gemm_tn(R, Cin, Cout, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(ws), wsb,
                                          _lib.stream_ptr()))
     return dw
+
+
+_pointwise_gemm_tn = torch.library.custom_op("sph3d::pointwise_gemm_tn", mutates_args=())(_pointwise_gemm_tn_impl)
 
 
 @_pointwise_gemm_tn.register_fake
@@ -88,7 +92,21 @@ def _gemm_backward(ctx, dy):
 _pointwise_gemm.register_autograd(_gemm_backward, setup_context=_gemm_setup)
 
 
+class _PointwiseGemmFn(torch.autograd.Function):      # eager fast path (see tf_conv3d._DepthwiseConv3dFn)
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return _pointwise_gemm_impl(x, w, False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = _pointwise_gemm_impl(dy, w, True) if ctx.needs_input_grad[0] else None
+        dw = _pointwise_gemm_tn_impl(x, dy) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
 def matmul(x, w):
     if _backend == "hip":
-        return _pointwise_gemm(x, w, False)
+        return _PointwiseGemmFn.apply(x, w)
     return torch.matmul(x, w)

@@ -11,8 +11,7 @@ import torch
 from . import _lib
 
 
-@torch.library.custom_op("sph3d::build_sphere_neighbor", mutates_args=())
-def _build_sphere_neighbor(database: torch.Tensor, query: torch.Tensor, radius: float,
+def _build_sphere_neighbor_impl(database: torch.Tensor, query: torch.Tensor, radius: float,
                            nn_sample: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     _lib.require_device(database, query)
     # shape checks of BuildSphereNeighborGpuOp::Compute (tf_nnquery.cpp:76-77)
@@ -32,6 +31,9 @@ def _build_sphere_neighbor(database: torch.Tensor, query: torch.Tensor, radius: 
     return nn_index, nn_count, nn_dist
 
 
+_build_sphere_neighbor = torch.library.custom_op("sph3d::build_sphere_neighbor", mutates_args=())(_build_sphere_neighbor_impl)
+
+
 @_build_sphere_neighbor.register_fake
 def _(database, query, radius, nn_sample):
     B, M = query.shape[0], query.shape[1]
@@ -40,8 +42,7 @@ def _(database, query, radius, nn_sample):
             database.new_empty((B, M, nn_sample), dtype=torch.float32))
 
 
-@torch.library.custom_op("sph3d::build_cube_neighbor", mutates_args=())
-def _build_cube_neighbor(database: torch.Tensor, query: torch.Tensor, length: float, nn_sample: int,
+def _build_cube_neighbor_impl(database: torch.Tensor, query: torch.Tensor, length: float, nn_sample: int,
                          grid_size: int) -> Tuple[torch.Tensor, torch.Tensor]:
     _lib.require_device(database, query)
     if database.dim() != 3 or database.shape[2] != 3:
@@ -57,6 +58,9 @@ def _build_cube_neighbor(database: torch.Tensor, query: torch.Tensor, length: fl
         B, N, M, grid_size, nn_sample, length, _lib.ptr(database), _lib.ptr(query),
         _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.stream_ptr()))
     return nn_index, nn_count
+
+
+_build_cube_neighbor = torch.library.custom_op("sph3d::build_cube_neighbor", mutates_args=())(_build_cube_neighbor_impl)
 
 
 @_build_cube_neighbor.register_fake
@@ -83,7 +87,7 @@ def build_sphere_neighbor(database, query, radius=0.1, dilation_rate=None, nnsam
     query = query[:, :, 0:3]
     if dilation_rate is not None:
         radius = dilation_rate * radius
-    return _build_sphere_neighbor(database, query, float(radius), int(nnsample))
+    return _build_sphere_neighbor_impl(database, query, float(radius), int(nnsample))
 
 
 def build_cube_neighbor(database, query, length=0.1, dilation_rate=None, nnsample=100, gridsize=3):
@@ -96,4 +100,4 @@ def build_cube_neighbor(database, query, length=0.1, dilation_rate=None, nnsampl
     query = query[:, :, 0:3]
     if dilation_rate is not None:
         length = dilation_rate * length
-    return _build_cube_neighbor(database, query, float(length), int(nnsample), int(gridsize))
+    return _build_cube_neighbor_impl(database, query, float(length), int(nnsample), int(gridsize))

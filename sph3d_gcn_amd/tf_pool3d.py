@@ -19,8 +19,7 @@ def _check_pool(input, nn_index, nn_count):
         raise ValueError("rank of nn_count should be 2")
 
 
-@torch.library.custom_op("sph3d::max_pool3d", mutates_args=())
-def _max_pool3d(input: torch.Tensor, nn_index: torch.Tensor, nn_count: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+def _max_pool3d_impl(input: torch.Tensor, nn_index: torch.Tensor, nn_count: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     _lib.require_device(input, nn_index, nn_count)
     _check_pool(input, nn_index, nn_count)
     input, nn_index, nn_count = _lib.f32(input), _lib.i32(nn_index), _lib.i32(nn_count)
@@ -33,14 +32,16 @@ def _max_pool3d(input: torch.Tensor, nn_index: torch.Tensor, nn_count: torch.Ten
     return output, max_index
 
 
+_max_pool3d = torch.library.custom_op("sph3d::max_pool3d", mutates_args=())(_max_pool3d_impl)
+
+
 @_max_pool3d.register_fake
 def _(input, nn_index, nn_count):
     shape = (input.shape[0], nn_index.shape[1], input.shape[2])
     return input.new_empty(shape), input.new_empty(shape, dtype=torch.int32)
 
 
-@torch.library.custom_op("sph3d::max_pool3d_grad", mutates_args=())
-def _max_pool3d_grad(input: torch.Tensor, grad_output: torch.Tensor, max_index: torch.Tensor) -> torch.Tensor:
+def _max_pool3d_grad_impl(input: torch.Tensor, grad_output: torch.Tensor, max_index: torch.Tensor) -> torch.Tensor:
     _lib.require_device(input, grad_output, max_index)
     grad_output, max_index = _lib.f32(grad_output), _lib.i32(max_index)
     B, N, C = input.shape
@@ -49,6 +50,9 @@ def _max_pool3d_grad(input: torch.Tensor, grad_output: torch.Tensor, max_index: 
     _lib.check(_lib.lib().sph3d_max_pool3d_grad(B, N, M, C, _lib.ptr(max_index), _lib.ptr(grad_output),
                                                 _lib.ptr(grad_input), _lib.stream_ptr()))
     return grad_input
+
+
+_max_pool3d_grad = torch.library.custom_op("sph3d::max_pool3d_grad", mutates_args=())(_max_pool3d_grad_impl)
 
 
 @_max_pool3d_grad.register_fake
@@ -69,8 +73,7 @@ def _max_backward(ctx, grad_output, grad_index):
 _max_pool3d.register_autograd(_max_backward, setup_context=_max_setup)
 
 
-@torch.library.custom_op("sph3d::avg_pool3d", mutates_args=())
-def _avg_pool3d(input: torch.Tensor, nn_index: torch.Tensor, nn_count: torch.Tensor) -> torch.Tensor:
+def _avg_pool3d_impl(input: torch.Tensor, nn_index: torch.Tensor, nn_count: torch.Tensor) -> torch.Tensor:
     _lib.require_device(input, nn_index, nn_count)
     _check_pool(input, nn_index, nn_count)
     input, nn_index, nn_count = _lib.f32(input), _lib.i32(nn_index), _lib.i32(nn_count)
@@ -82,13 +85,15 @@ def _avg_pool3d(input: torch.Tensor, nn_index: torch.Tensor, nn_count: torch.Ten
     return output
 
 
+_avg_pool3d = torch.library.custom_op("sph3d::avg_pool3d", mutates_args=())(_avg_pool3d_impl)
+
+
 @_avg_pool3d.register_fake
 def _(input, nn_index, nn_count):
     return input.new_empty((input.shape[0], nn_index.shape[1], input.shape[2]))
 
 
-@torch.library.custom_op("sph3d::avg_pool3d_grad", mutates_args=())
-def _avg_pool3d_grad(input: torch.Tensor, grad_output: torch.Tensor, nn_index: torch.Tensor,
+def _avg_pool3d_grad_impl(input: torch.Tensor, grad_output: torch.Tensor, nn_index: torch.Tensor,
                      nn_count: torch.Tensor) -> torch.Tensor:
     _lib.require_device(input, grad_output, nn_index, nn_count)
     grad_output, nn_index, nn_count = _lib.f32(grad_output), _lib.i32(nn_index), _lib.i32(nn_count)
@@ -99,6 +104,9 @@ def _avg_pool3d_grad(input: torch.Tensor, grad_output: torch.Tensor, nn_index: t
     _lib.check(_lib.lib().sph3d_scatter_grad_t(B, N, M, C, _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale),
                                                _lib.ptr(grad_output), _lib.ptr(grad_input), _lib.stream_ptr()))
     return grad_input
+
+
+_avg_pool3d_grad = torch.library.custom_op("sph3d::avg_pool3d_grad", mutates_args=())(_avg_pool3d_grad_impl)
 
 
 @_avg_pool3d_grad.register_fake
@@ -118,17 +126,43 @@ def _avg_backward(ctx, grad_output):
 _avg_pool3d.register_autograd(_avg_backward, setup_context=_avg_setup)
 
 
+class _MaxPool3dFn(torch.autograd.Function):      # eager fast path (see tf_conv3d._DepthwiseConv3dFn)
+    @staticmethod
+    def forward(ctx, input, nn_index, nn_count):
+        output, max_index = _max_pool3d_impl(input, nn_index, nn_count)
+        ctx.save_for_backward(input, max_index)
+        ctx.mark_non_differentiable(max_index)
+        return output, max_index
+
+    @staticmethod
+    def backward(ctx, grad_output, grad_index):
+        input, max_index = ctx.saved_tensors
+        return _max_pool3d_grad_impl(input, grad_output, max_index), None, None
+
+
+class _AvgPool3dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, nn_index, nn_count):
+        ctx.save_for_backward(input, nn_index, nn_count)
+        return _avg_pool3d_impl(input, nn_index, nn_count)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, nn_index, nn_count = ctx.saved_tensors
+        return _avg_pool3d_grad_impl(input, grad_output, nn_index, nn_count), None, None
+
+
 def max_pool3d(input, nn_index, nn_count):
-    return _max_pool3d(input, nn_index, nn_count)
+    return _MaxPool3dFn.apply(input, nn_index, nn_count)
 
 
 def max_pool3d_grad(input, grad_output, max_index):
-    return _max_pool3d_grad(input, grad_output, max_index)
+    return _max_pool3d_grad_impl(input, grad_output, max_index)
 
 
 def avg_pool3d(input, nn_index, nn_count):
-    return _avg_pool3d(input, nn_index, nn_count)
+    return _AvgPool3dFn.apply(input, nn_index, nn_count)
 
 
 def avg_pool3d_grad(input, grad_output, nn_index, nn_count):
-    return _avg_pool3d_grad(input, grad_output, nn_index, nn_count)
+    return _avg_pool3d_grad_impl(input, grad_output, nn_index, nn_count)

@@ -9,8 +9,7 @@ import torch
 from . import _lib
 
 
-@torch.library.custom_op("sph3d::farthest_point_sample", mutates_args=())
-def _farthest_point_sample(database: torch.Tensor, npoint: int) -> torch.Tensor:
+def _farthest_point_sample_impl(database: torch.Tensor, npoint: int) -> torch.Tensor:
     _lib.require_device(database)
     if npoint <= 0:
         raise ValueError("FarthestPointSample expects positive npoint")                     # tf_sample.cpp:35
@@ -27,6 +26,9 @@ def _farthest_point_sample(database: torch.Tensor, npoint: int) -> torch.Tensor:
     return out
 
 
+_farthest_point_sample = torch.library.custom_op("sph3d::farthest_point_sample", mutates_args=())(_farthest_point_sample_impl)
+
+
 @_farthest_point_sample.register_fake
 def _(database, npoint):
     return database.new_empty((database.shape[0], npoint), dtype=torch.int32)
@@ -40,7 +42,7 @@ def farthest_point_sample(neursize, database):
     returns:
         neuron_index: (batch_size, neursize) int32 array, index of sampled neurons in the database
     '''
-    return _farthest_point_sample(database, int(neursize))
+    return _farthest_point_sample_impl(database, int(neursize))
 
 
 def inverse_density_sample(neursize, probability):

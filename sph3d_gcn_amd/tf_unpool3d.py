@@ -17,8 +17,7 @@ def _check(input, nn_index, nn_count):
         raise ValueError("rank of nn_count should be 2")
 
 
-@torch.library.custom_op("sph3d::mean_interpolate", mutates_args=())
-def _mean_interpolate(input: torch.Tensor, nn_index: torch.Tensor, nn_count: torch.Tensor) -> torch.Tensor:
+def _mean_interpolate_impl(input: torch.Tensor, nn_index: torch.Tensor, nn_count: torch.Tensor) -> torch.Tensor:
     _lib.require_device(input, nn_index, nn_count)
     _check(input, nn_index, nn_count)
     input, nn_index, nn_count = _lib.f32(input), _lib.i32(nn_index), _lib.i32(nn_count)
@@ -30,13 +29,15 @@ def _mean_interpolate(input: torch.Tensor, nn_index: torch.Tensor, nn_count: tor
     return output
 
 
+_mean_interpolate = torch.library.custom_op("sph3d::mean_interpolate", mutates_args=())(_mean_interpolate_impl)
+
+
 @_mean_interpolate.register_fake
 def _(input, nn_index, nn_count):
     return input.new_empty((input.shape[0], nn_index.shape[1], input.shape[2]))
 
 
-@torch.library.custom_op("sph3d::mean_interpolate_grad", mutates_args=())
-def _mean_interpolate_grad(input: torch.Tensor, grad_output: torch.Tensor, nn_index: torch.Tensor,
+def _mean_interpolate_grad_impl(input: torch.Tensor, grad_output: torch.Tensor, nn_index: torch.Tensor,
                            nn_count: torch.Tensor) -> torch.Tensor:
     _lib.require_device(input, grad_output, nn_index, nn_count)
     grad_output, nn_index, nn_count = _lib.f32(grad_output), _lib.i32(nn_index), _lib.i32(nn_count)
@@ -47,6 +48,9 @@ def _mean_interpolate_grad(input: torch.Tensor, grad_output: torch.Tensor, nn_in
     _lib.check(_lib.lib().sph3d_scatter_grad_t(B, M, N, C, _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale),
                                                _lib.ptr(grad_output), _lib.ptr(grad_input), _lib.stream_ptr()))
     return grad_input
+
+
+_mean_interpolate_grad = torch.library.custom_op("sph3d::mean_interpolate_grad", mutates_args=())(_mean_interpolate_grad_impl)
 
 
 @_mean_interpolate_grad.register_fake
@@ -66,8 +70,7 @@ def _mean_backward(ctx, grad_output):
 _mean_interpolate.register_autograd(_mean_backward, setup_context=_mean_setup)
 
 
-@torch.library.custom_op("sph3d::weighted_interpolate", mutates_args=())
-def _weighted_interpolate(input: torch.Tensor, weight: torch.Tensor, nn_index: torch.Tensor,
+def _weighted_interpolate_impl(input: torch.Tensor, weight: torch.Tensor, nn_index: torch.Tensor,
                           nn_count: torch.Tensor) -> torch.Tensor:
     _lib.require_device(input, weight, nn_index, nn_count)
     _check(input, nn_index, nn_count)
@@ -82,13 +85,15 @@ def _weighted_interpolate(input: torch.Tensor, weight: torch.Tensor, nn_index: t
     return output
 
 
+_weighted_interpolate = torch.library.custom_op("sph3d::weighted_interpolate", mutates_args=())(_weighted_interpolate_impl)
+
+
 @_weighted_interpolate.register_fake
 def _(input, weight, nn_index, nn_count):
     return input.new_empty((input.shape[0], nn_index.shape[1], input.shape[2]))
 
 
-@torch.library.custom_op("sph3d::weighted_interpolate_grad", mutates_args=())
-def _weighted_interpolate_grad(input: torch.Tensor, grad_output: torch.Tensor, weight: torch.Tensor,
+def _weighted_interpolate_grad_impl(input: torch.Tensor, grad_output: torch.Tensor, weight: torch.Tensor,
                                nn_index: torch.Tensor, nn_count: torch.Tensor) -> torch.Tensor:
     _lib.require_device(input, grad_output, weight, nn_index, nn_count)
     grad_output, weight = _lib.f32(grad_output), _lib.f32(weight)
@@ -100,6 +105,9 @@ def _weighted_interpolate_grad(input: torch.Tensor, grad_output: torch.Tensor, w
     _lib.check(_lib.lib().sph3d_scatter_grad_t(B, M, N, C, _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale),
                                                _lib.ptr(grad_output), _lib.ptr(grad_input), _lib.stream_ptr()))
     return grad_input
+
+
+_weighted_interpolate_grad = torch.library.custom_op("sph3d::weighted_interpolate_grad", mutates_args=())(_weighted_interpolate_grad_impl)
 
 
 @_weighted_interpolate_grad.register_fake
@@ -119,17 +127,41 @@ def _w_backward(ctx, grad_output):
 _weighted_interpolate.register_autograd(_w_backward, setup_context=_w_setup)
 
 
+class _MeanInterpolateFn(torch.autograd.Function):      # eager fast path (see tf_conv3d._DepthwiseConv3dFn)
+    @staticmethod
+    def forward(ctx, input, nn_index, nn_count):
+        ctx.save_for_backward(input, nn_index, nn_count)
+        return _mean_interpolate_impl(input, nn_index, nn_count)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, nn_index, nn_count = ctx.saved_tensors
+        return _mean_interpolate_grad_impl(input, grad_output, nn_index, nn_count), None, None
+
+
+class _WeightedInterpolateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, weight, nn_index, nn_count):
+        ctx.save_for_backward(input, weight, nn_index, nn_count)
+        return _weighted_interpolate_impl(input, weight, nn_index, nn_count)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, weight, nn_index, nn_count = ctx.saved_tensors
+        return _weighted_interpolate_grad_impl(input, grad_output, weight, nn_index, nn_count), None, None, None
+
+
 def mean_interpolate(input, nn_index, nn_count):
-    return _mean_interpolate(input, nn_index, nn_count)
+    return _MeanInterpolateFn.apply(input, nn_index, nn_count)
 
 
 def mean_interpolate_grad(input, grad_output, nn_index, nn_count):
-    return _mean_interpolate_grad(input, grad_output, nn_index, nn_count)
+    return _mean_interpolate_grad_impl(input, grad_output, nn_index, nn_count)
 
 
 def weighted_interpolate(input, weight, nn_index, nn_count):
-    return _weighted_interpolate(input, weight, nn_index, nn_count)
+    return _WeightedInterpolateFn.apply(input, weight, nn_index, nn_count)
 
 
 def weighted_interpolate_grad(input, grad_output, weight, nn_index, nn_count):
-    return _weighted_interpolate_grad(input, grad_output, weight, nn_index, nn_count)
+    return _weighted_interpolate_grad_impl(input, grad_output, weight, nn_index, nn_count)

@@ -377,3 +377,44 @@ def test_cabi_gradient_wrappers_with_workspace(dev):
     assert l.sph3d_weighted_interpolate_grad(B, N, M, C, K, P(ut), P(uct), P(gut), P(wgt_t), P(g3), P(ws), wsb,
                                              _lib.stream_ptr()) == 0
     np.testing.assert_allclose(_n(g3), oracle.weighted_interpolate_grad(feat, gu, wgt, uidx, ucnt), **TOL)
+
+
+GEMM_CASES = [(1000, 3, 64), (4096, 128, 128), (3000, 256, 13), (777, 70, 64), (2048, 1024, 512), (130, 131, 128),
+              (5000, 2048, 256), (16384, 64, 40)]
+
+
+@pytest.mark.parametrize("case", GEMM_CASES, ids=lambda c: "R%d-Cin%d-Cout%d" % c)
+def test_pointwise_gemm_forward_backward(dev, case):
+    """fp32 MFMA GEMM (exact fp32) vs float64 numpy: 1e-5 relative to the row scale; asymmetric operands so a
+    transposed fragment / C-layout mix-up cannot pass."""
+    from sph3d_gcn_amd import tf_gemm
+    R, Cin, Cout = case
+    rng = np.random.RandomState(R + Cin)
+    x = rng.randn(R, Cin).astype(np.float32)
+    w = (rng.randn(Cin, Cout) * (1 + np.arange(Cout))[None, :] * 0.1).astype(np.float32)
+    dy = rng.randn(R, Cout).astype(np.float32)
+    xt = _t(x, dev).requires_grad_(True)
+    wt = _t(w, dev).requires_grad_(True)
+    y = tf_gemm._pointwise_gemm(xt, wt, False)
+    y64 = x.astype(np.float64) @ w.astype(np.float64)
+    s = max(1.0, float(np.abs(y64).max()))
+    np.testing.assert_allclose(_n(y) / s, y64 / s, rtol=1e-5, atol=1e-5)
+    y.backward(_t(dy, dev))
+    dx64 = dy.astype(np.float64) @ w.astype(np.float64).T
+    dw64 = x.astype(np.float64).T @ dy.astype(np.float64)
+    s = max(1.0, float(np.abs(dx64).max()))
+    np.testing.assert_allclose(_n(xt.grad) / s, dx64 / s, rtol=1e-5, atol=1e-5)
+    s = max(1.0, float(np.abs(dw64).max()))
+    np.testing.assert_allclose(_n(wt.grad) / s, dw64 / s, rtol=1e-5, atol=2e-5)
+
+
+def test_pointwise_gemm_bias_elu_epilogue(dev):
+    R, Cin, Cout = 1500, 96, 72
+    rng = np.random.RandomState(1)
+    x, w, b = rng.randn(R, Cin).astype(np.float32), rng.randn(Cin, Cout).astype(np.float32), rng.randn(Cout).astype(np.float32)
+    xt, wt, bt = _t(x, dev), _t(w, dev), _t(b, dev)
+    y = torch.empty((R, Cout), device=dev)
+    _lib.check(_lib.lib().sph3d_pointwise_gemm(R, Cin, Cout, _lib.ptr(xt), _lib.ptr(wt), _lib.ptr(bt), 1, 0, _lib.ptr(y),
+                                               _lib.stream_ptr()))
+    ref = torch.nn.functional.elu(xt.double() @ wt.double() + bt.double())
+    torch.testing.assert_close(y.double(), ref, rtol=1e-5, atol=2e-5)
