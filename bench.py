@@ -20,6 +20,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")   # cpu_baseline leg: two OpenMP pools (torch, oracle) must not spin against each other
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -138,35 +140,47 @@ class GraphedStep:
         return self.loss
 
 
-def cpu_baseline(seconds_target=12.0, sample_blocks=2):
-    """Same harness step on the CPU oracle (kind = "port").  Bounded: `sample_blocks` S3DIS blocks per step,
-    repeated until ~seconds_target of CPU work (at least one step after one warm-up-free cold step)."""
+def cpu_baseline(sample_blocks=4, budget_s=30.0):
+    """Same harness step (graph build + fwd + bwd + Adam) on the CPU oracle — kind = "port": oracle/ is the C
+    restatement of the reference's kernels, OpenMP across independent work items; GEMM / BN / ELU run in torch-CPU
+    (MKL/oneDNN) so the baseline is not handicapped.  Bounded sample: `sample_blocks` S3DIS-like blocks per step; one
+    untimed step creates the variables, then one timed step per candidate thread count (all hardware threads, physical
+    cores, half of them) and the fastest is reported with the thread count it used."""
     import oracle  # noqa: F401  (cpu_baseline leg: the oracle is the thing timed here, by design)
     from oracle import torch_ops
-    cores = os.cpu_count() or 1
+    hw = os.cpu_count() or 1
+    phys = hw // 2 if hw >= 16 else hw
+    cands = []
+    for c in (phys, hw, max(1, phys // 2)):
+        if c not in cands:
+            cands.append(c)
     xyz, label, inner = synth.s3dis_batch(5000, sample_blocks, NUM_POINT)
     pts, label, inner = torch.from_numpy(xyz), torch.from_numpy(label), torch.from_numpy(inner)
-    torch.set_num_threads(cores)
+    t_start = time.perf_counter()
+    best = None
     with torch_ops.patched_util():
         model = s3dis_net.SPH3DS3DIS(s3dis_net.s3dis_config(NUM_POINT), device=torch.device("cpu"))
-        with torch.no_grad():
-            pass
-        # one cold step creates the variables (not timed), then the optimiser
-        graphs = s3dis_net.build_graphs(pts, model.config)
-        pred, _ = model(pts, is_training=True, graphs=graphs)
-        model.loss(pred, label, inner).backward()
+        oracle.set_num_threads(cands[0])
+        torch.set_num_threads(cands[0])
+        pred, _ = model(pts, is_training=True)
+        model.loss(pred, label, inner).backward()                       # cold step: creates the variables
         flat = hdist.FlatGradAllReduce(model.parameters())
         opt = torch.optim.Adam([flat.flat_param], lr=1e-3, eps=1e-4)
-        steps, t0 = 0, time.perf_counter()
-        while True:
-            train_step(model, flat, opt, pts, label, inner)
-            steps += 1
-            el = time.perf_counter() - t0
-            if el >= seconds_target or steps >= 20:
+        for c in cands:
+            if best is not None and (time.perf_counter() - t_start) > budget_s:
                 break
-    return {"value": round(steps * sample_blocks / el, 4), "unit": "blocks/s", "cores": cores, "kind": "port",
-            "sample": "%d step(s) x %d S3DIS-like 8192-pt blocks, full SPH3D_s3dis fwd+bwd+Adam on oracle/ "
-                      "(C, OpenMP) with torch-CPU GEMM/BN, %.1f s" % (steps, sample_blocks, el)}
+            oracle.set_num_threads(c)
+            torch.set_num_threads(c)
+            t0 = time.perf_counter()
+            train_step(model, flat, opt, pts, label, inner)
+            el = time.perf_counter() - t0
+            if best is None or el < best[0]:
+                best = (el, c)
+    el, c = best
+    return {"value": round(sample_blocks / el, 4), "unit": "blocks/s", "cores": c, "kind": "port",
+            "sample": "1 timed step x %d S3DIS-like 8192-pt blocks (full SPH3D_s3dis graph build + fwd + bwd + Adam on "
+                      "oracle/ C+OpenMP, torch-CPU GEMM/BN), best of thread counts %s on a %d-thread host, %.2f s/step"
+                      % (sample_blocks, cands, hw, el)}
 
 
 def main():

@@ -52,6 +52,15 @@ def lib():
     return _lib
 
 
+def set_num_threads(n):
+    """OpenMP threads used by the oracle (bench.py's cpu_baseline leg picks the best-performing count)."""
+    lib().oracle_set_num_threads(_c_int(int(n)))
+
+
+def get_max_threads():
+    return int(lib().oracle_get_max_threads())
+
+
 def _f(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 

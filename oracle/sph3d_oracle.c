@@ -44,6 +44,15 @@ static int imin(int a, int b) { return a < b ? a : b; }
 
 int oracle_abi_version(void) { return 1; }
 
+#ifdef _OPENMP
+#include <omp.h>
+void oracle_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int oracle_get_max_threads(void) { return omp_get_max_threads(); }
+#else
+void oracle_set_num_threads(int n) { (void)n; }
+int oracle_get_max_threads(void) { return 1; }
+#endif
+
 /* ------------------------------------------------------------------------
  * cal_nn_binidx — tf_ops/nnquery/tf_nnquery_gpu.cu:15-65
  * Outputs zeroed first (tf_nnquery.cpp:100-102).
@@ -245,12 +254,18 @@ int oracle_depthwise_conv3d_grad(int B, int N, int M, int F, int C, int r, int K
     const int CR = C * r;
     memset(gradInput, 0, sizeof(float) * (size_t)B * N * C);
     memset(gradFilter, 0, sizeof(float) * (size_t)F * CR);
-    const int chunk = 8;
+    /* work item = (cloud i, slice of input channels): gradInput[i, :, slice] is private to it; the filter gradient
+     * is accumulated per cloud (gfPart[i]) and the clouds are added afterwards in order i = 0..B-1, so the result
+     * does not depend on the thread count */
+    const int chunk = 4;
     const int nchunks = (C + chunk - 1) / chunk;
-#pragma omp parallel for schedule(dynamic, 1)
-    for (int ch = 0; ch < nchunks; ch++) {
-        const int c0 = ch * chunk, c1 = imin(C, c0 + chunk);
-        for (int i = 0; i < B; i++) {
+    float* gfPart = (float*)calloc((size_t)B * F * CR, sizeof(float));
+    if (!gfPart) return ORACLE_EINVAL;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int i = 0; i < B; i++) {
+        for (int ch = 0; ch < nchunks; ch++) {
+            const int c0 = ch * chunk, c1 = imin(C, c0 + chunk);
+            float* gfi = gfPart + (size_t)i * F * CR;
             for (int m = 0; m < M; m++) {
                 const int nnSize = nnCount[(size_t)i * M + m];
                 const float* go = gradOutput + ((size_t)i * M + m) * CR;
@@ -263,13 +278,20 @@ int oracle_depthwise_conv3d_grad(int B, int N, int M, int F, int C, int r, int K
                         for (int rr = 0; rr < r; rr++) {
                             const int cout = cin * r + rr;
                             gi[cin] += go[cout] * filter[(size_t)f * CR + cout] / nnSize;   /* :50-51 */
-                            gradFilter[(size_t)f * CR + cout] += go[cout] * in[cin] / nnSize; /* :87 */
+                            gfi[(size_t)f * CR + cout] += go[cout] * in[cin] / nnSize;       /* :87 */
                         }
                     }
                 }
             }
         }
     }
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < F * CR; j++) {
+        float s = 0.0f;
+        for (int i = 0; i < B; i++) s += gfPart[(size_t)i * F * CR + j];
+        gradFilter[j] = s;
+    }
+    free(gfPart);
     return ORACLE_OK;
 }
 
@@ -305,10 +327,10 @@ int oracle_max_pool3d_grad(int B, int N, int M, int C,
                            const int* maxIndex, const float* gradOutput, float* gradInput)
 {
     memset(gradInput, 0, sizeof(float) * (size_t)B * N * C);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for collapse(2) schedule(static)
     for (int i = 0; i < B; i++) {
-        for (int m = 0; m < M; m++) {
-            for (int c = 0; c < C; c++) {
+        for (int c = 0; c < C; c++) {          /* work item = (cloud, channel): private output column */
+            for (int m = 0; m < M; m++) {
                 const int n = maxIndex[((size_t)i * M + m) * C + c];
                 gradInput[((size_t)i * N + n) * C + c] += gradOutput[((size_t)i * M + m) * C + c];
             }
@@ -343,15 +365,19 @@ int oracle_avg_pool3d_grad(int B, int N, int M, int C, int K,
                            float* gradInput)
 {
     memset(gradInput, 0, sizeof(float) * (size_t)B * N * C);
-#pragma omp parallel for schedule(static)
+    const int nch = (C + 7) / 8;      /* work item = (cloud, 8-channel slice): private output slice */
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int i = 0; i < B; i++) {
-        for (int m = 0; m < M; m++) {
-            const int nnSize = nnCount[(size_t)i * M + m];
-            const float* go = gradOutput + ((size_t)i * M + m) * C;
-            for (int k = 0; k < nnSize; k++) {
-                const int n = nnIndex[((size_t)i * M + m) * K + k];
-                float* gi = gradInput + ((size_t)i * N + n) * C;
-                for (int c = 0; c < C; c++) gi[c] += go[c] / nnSize;
+        for (int ch = 0; ch < nch; ch++) {
+            const int c0 = ch * 8, c1 = imin(C, c0 + 8);
+            for (int m = 0; m < M; m++) {
+                const int nnSize = nnCount[(size_t)i * M + m];
+                const float* go = gradOutput + ((size_t)i * M + m) * C;
+                for (int k = 0; k < nnSize; k++) {
+                    const int n = nnIndex[((size_t)i * M + m) * K + k];
+                    float* gi = gradInput + ((size_t)i * N + n) * C;
+                    for (int c = c0; c < c1; c++) gi[c] += go[c] / nnSize;
+                }
             }
         }
     }
@@ -386,15 +412,19 @@ int oracle_mean_interpolate_grad(int B, int N, int M, int C, int K,
                                  float* gradInput)
 {
     memset(gradInput, 0, sizeof(float) * (size_t)B * M * C);
-#pragma omp parallel for schedule(static)
+    const int nch = (C + 7) / 8;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int i = 0; i < B; i++) {
-        for (int n = 0; n < N; n++) {
-            const int nnSize = nnCount[(size_t)i * N + n];
-            const float* go = gradOutput + ((size_t)i * N + n) * C;
-            for (int k = 0; k < nnSize; k++) {
-                const int m = nnIndex[((size_t)i * N + n) * K + k];
-                float* gi = gradInput + ((size_t)i * M + m) * C;
-                for (int c = 0; c < C; c++) gi[c] += go[c] / nnSize;
+        for (int ch = 0; ch < nch; ch++) {
+            const int c0 = ch * 8, c1 = imin(C, c0 + 8);
+            for (int n = 0; n < N; n++) {
+                const int nnSize = nnCount[(size_t)i * N + n];
+                const float* go = gradOutput + ((size_t)i * N + n) * C;
+                for (int k = 0; k < nnSize; k++) {
+                    const int m = nnIndex[((size_t)i * N + n) * K + k];
+                    float* gi = gradInput + ((size_t)i * M + m) * C;
+                    for (int c = c0; c < c1; c++) gi[c] += go[c] / nnSize;
+                }
             }
         }
     }
@@ -429,16 +459,20 @@ int oracle_weighted_interpolate_grad(int B, int N, int M, int C, int K,
                                      float* gradInput)
 {
     memset(gradInput, 0, sizeof(float) * (size_t)B * M * C);
-#pragma omp parallel for schedule(static)
+    const int nch = (C + 7) / 8;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int i = 0; i < B; i++) {
-        for (int n = 0; n < N; n++) {
-            const int nnSize = nnCount[(size_t)i * N + n];
-            const float* go = gradOutput + ((size_t)i * N + n) * C;
-            for (int k = 0; k < nnSize; k++) {
-                const int m = nnIndex[((size_t)i * N + n) * K + k];
-                const float w = weight[((size_t)i * N + n) * K + k];
-                float* gi = gradInput + ((size_t)i * M + m) * C;
-                for (int c = 0; c < C; c++) gi[c] += go[c] * w;
+        for (int ch = 0; ch < nch; ch++) {
+            const int c0 = ch * 8, c1 = imin(C, c0 + 8);
+            for (int n = 0; n < N; n++) {
+                const int nnSize = nnCount[(size_t)i * N + n];
+                const float* go = gradOutput + ((size_t)i * N + n) * C;
+                for (int k = 0; k < nnSize; k++) {
+                    const int m = nnIndex[((size_t)i * N + n) * K + k];
+                    const float w = weight[((size_t)i * N + n) * K + k];
+                    float* gi = gradInput + ((size_t)i * M + m) * C;
+                    for (int c = c0; c < c1; c++) gi[c] += go[c] * w;
+                }
             }
         }
     }
