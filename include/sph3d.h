@@ -216,6 +216,23 @@ int sph3d_pointwise_gemm_tn(int R, int Cin, int Cout,
                             sph3d_stream_t stream);
 size_t sph3d_pointwise_gemm_tn_workspace(int R, int Cin, int Cout);
 
+/* ---- fused ELU + batch-norm tail of separable_conv3d / pointwise_conv3d --------------------------
+ * replaces tf.nn.elu + tf.layers.batch_normalization(momentum=0.99, epsilon=1e-3) applied after the
+ * pointwise matmul (utils/sph3gcn_util.py:152-161, 208-220, 328-332; stock TF ops in the reference).
+ * y[R,C] is the matmul output; out = (elu(y) - mean) * rstd * gamma + beta with per-channel statistics of
+ * elu(y) over the R rows (training) or the running statistics (inference).  `momentum` is the weight of
+ * the NEW batch statistics (1 - 0.99).  save_mean / save_rstd [C] feed the backward pass, which needs only
+ * y (elu(y) is recomputed).  Requires C % 4 == 0 and C <= 1024.  workspace: sph3d_elu_bn_workspace(). */
+size_t sph3d_elu_bn_workspace(int R, int C);
+int sph3d_elu_bn_forward(int R, int C, const float* y, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float momentum, float eps, int training,
+                         float* out, float* save_mean, float* save_rstd,
+                         void* workspace, size_t workspace_bytes, sph3d_stream_t stream);
+int sph3d_elu_bn_backward(int R, int C, const float* y, const float* dout, const float* gamma,
+                          const float* save_mean, const float* save_rstd, int training,
+                          float* dy, float* dgamma, float* dbeta,
+                          void* workspace, size_t workspace_bytes, sph3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ Layout (only what the path needs):
   harness/         torch re-statement of the model graphs' call pattern, used by bench/smoke only
 """
 from . import _lib  # noqa: F401
-from . import tf_nnquery, tf_buildkernel, tf_conv3d, tf_pool3d, tf_unpool3d, tf_sample, tf_gemm  # noqa: F401
+from . import tf_nnquery, tf_buildkernel, tf_conv3d, tf_pool3d, tf_unpool3d, tf_sample, tf_gemm, tf_norm  # noqa: F401
 from . import sph3gcn_util  # noqa: F401
 
 __all__ = ["tf_nnquery", "tf_buildkernel", "tf_conv3d", "tf_pool3d", "tf_unpool3d", "tf_sample", "tf_gemm",

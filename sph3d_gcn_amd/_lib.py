@@ -48,6 +48,9 @@ SIGNATURES = {
     "sph3d_pointwise_gemm": (_I, [_I] * 3 + [_P, _P, _P, _I, _I, _P, _P]),
     "sph3d_pointwise_gemm_tn_workspace": (_S, [_I] * 3),
     "sph3d_pointwise_gemm_tn": (_I, [_I] * 3 + [_P, _P, _P, _P, _S, _P]),
+    "sph3d_elu_bn_workspace": (_S, [_I] * 2),
+    "sph3d_elu_bn_forward": (_I, [_I, _I, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _S, _P]),
+    "sph3d_elu_bn_backward": (_I, [_I, _I] + [_P] * 5 + [_I] + [_P] * 3 + [_P, _S, _P]),
 }
 # test-only hook exported by the library but not part of the reference surface
 _EXTRA = {
@@ -76,7 +79,7 @@ def lib():
             try:
                 fn = getattr(l, name)
             except AttributeError:
-                if table is SIGNATURES and not name.startswith("sph3d_pointwise_gemm"):
+                if table is SIGNATURES:
                     raise Sph3dError("libsph3d.so does not export %s" % name)
                 continue
             fn.restype = res

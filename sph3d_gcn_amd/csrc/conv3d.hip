@@ -23,6 +23,7 @@
 //   * Numerics: sum_k in*filt in fp32 FMA order k = 0..cnt-1, one division by cnt at the end (the
 //     reference divides every term); agreement with the oracle is ~1e-7 relative, bound 1e-5.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace sph3d {
 
@@ -522,6 +523,8 @@ extern "C" size_t sph3d_depthwise_conv3d_grad_workspace(int B, int N, int M, int
 static int vec_plan(int F, int CR, int r, int& V)
 {
     if (!(r == 1 || r == 2)) return 0;
+    static const int forced = getenv("SPH3D_BWD_V") ? atoi(getenv("SPH3D_BWD_V")) : 0;
+    if (forced == 2 && F <= 33 && CR % 2 == 0) { V = 2; return 1; }
     if (F <= 33 && CR % 4 == 0) { V = 4; return 1; }
     if (F <= 65 && CR % 2 == 0) { V = 2; return 1; }
     return 0;
@@ -585,6 +588,8 @@ extern "C" int sph3d_depthwise_conv3d_grad_t(int B, int N, int M, int F, int C, 
                                         grad_input, grad_filter, partial, st)
         if (V == 4 && r == 2) SPH3D_GO(2, 4, 33);
         if (V == 4 && r == 1) SPH3D_GO(1, 4, 33);
+        if (V == 2 && F <= 33 && r == 2) SPH3D_GO(2, 2, 33);
+        if (V == 2 && F <= 33 && r == 1) SPH3D_GO(1, 2, 33);
         if (V == 2 && r == 2) SPH3D_GO(2, 2, 65);
         SPH3D_GO(1, 2, 65);
 #undef SPH3D_GO

@@ -22,7 +22,7 @@ from . import tf_conv3d, tf_pool3d, tf_unpool3d
 from .tf_nnquery import build_sphere_neighbor, build_cube_neighbor
 from .tf_sample import farthest_point_sample, inverse_density_sample, random_sample
 from .tf_buildkernel import spherical_kernel
-from . import tf_gemm
+from . import tf_gemm, tf_norm
 
 neighbor_fn = build_sphere_neighbor  # default nn search method
 
@@ -198,6 +198,9 @@ def _finish(outputs, num_out_channels, scope, activation_fn, with_bn, with_bias,
     if with_bias and fused_bias is None:
         biases = get_variable_store().get_variable(scope + '/biases', [num_out_channels], _constant(0.0))
         outputs = outputs + biases
+    if (with_bn and activation_fn is elu and FUSE_ELU_BN and outputs.is_cuda and tf_norm.supported(outputs.shape[-1])):
+        # the reference's tail "ELU -> batch norm" (util.py:155-161) as ONE fused op on the HIP path
+        return _elu_batch_normalization(outputs, is_training, name=scope + '/bn')
     if activation_fn is not None:
         outputs = activation_fn(outputs)
     if with_bn:
@@ -306,11 +309,10 @@ def unpool3d(inputs, nn_index, nn_count, nn_dist, scope, method):
     return outputs
 
 
-def batch_normalization(data, is_training, name, reuse=None):
-    """tf.layers.batch_normalization(momentum=0.99, epsilon=1e-3 [TF default], axis=-1) with the
-    l2 regularisers on beta/gamma (utils/sph3gcn_util.py:328-332).  Statistics over all but the last axis."""
-    store = get_variable_store()
-    C = data.shape[-1]
+FUSE_ELU_BN = True     # fused sph3d::elu_bn for the ELU -> BN tail (same variables / moving statistics as the unfused ops)
+
+
+def _bn_variables(store, name, C):
     new = not store.has(name + '/gamma')
     gamma = store.get_variable(name + '/gamma', [C], _constant(1.0))
     beta = store.get_variable(name + '/beta', [C], _constant(0.0))
@@ -318,6 +320,22 @@ def batch_normalization(data, is_training, name, reuse=None):
         store._reg.extend([name + '/gamma', name + '/beta'])
     moving_mean = store.get_buffer(name + '/moving_mean', (C,), 0.0)
     moving_var = store.get_buffer(name + '/moving_variance', (C,), 1.0)
+    return gamma, beta, moving_mean, moving_var
+
+
+def _elu_batch_normalization(data, is_training, name):
+    store = get_variable_store()
+    gamma, beta, moving_mean, moving_var = _bn_variables(store, name, data.shape[-1])
+    training = True if is_training is None else bool(is_training)
+    return tf_norm.elu_batch_norm(data, gamma, beta, moving_mean, moving_var, training)
+
+
+def batch_normalization(data, is_training, name, reuse=None):
+    """tf.layers.batch_normalization(momentum=0.99, epsilon=1e-3 [TF default], axis=-1) with the
+    l2 regularisers on beta/gamma (utils/sph3gcn_util.py:328-332).  Statistics over all but the last axis."""
+    store = get_variable_store()
+    C = data.shape[-1]
+    gamma, beta, moving_mean, moving_var = _bn_variables(store, name, C)
     training = True if is_training is None else bool(is_training)
     flat = data.reshape(-1, C)
     out = F.batch_norm(flat, moving_mean, moving_var, gamma, beta, training=training, momentum=1.0 - 0.99, eps=1e-3)

@@ -418,3 +418,29 @@ def test_pointwise_gemm_bias_elu_epilogue(dev):
                                                _lib.stream_ptr()))
     ref = torch.nn.functional.elu(xt.double() @ wt.double() + bt.double())
     torch.testing.assert_close(y.double(), ref, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("R,C", [(1000, 64), (4096, 128), (777, 192), (20000, 512), (131072, 128)])
+def test_fused_elu_batch_norm(dev, R, C):
+    """sph3d::elu_bn == torch elu -> batch_norm (training and inference), forward, backward, moving statistics."""
+    from sph3d_gcn_amd import tf_norm
+    g = torch.Generator(device="cpu").manual_seed(R + C)
+    y = (torch.randn(R, C, generator=g) * 2 - 0.3).to(dev)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+    beta = torch.randn(C, generator=g).to(dev)
+    dout = torch.randn(R, C, generator=g).to(dev)
+    for training in (True, False):
+        mm, mv = torch.zeros(C, device=dev) + 0.1, torch.ones(C, device=dev) * 0.7
+        mm2, mv2 = mm.clone(), mv.clone()
+        y1 = y.clone().requires_grad_(True); g1 = gamma.clone().requires_grad_(True); b1 = beta.clone().requires_grad_(True)
+        y2 = y.clone().requires_grad_(True); g2 = gamma.clone().requires_grad_(True); b2 = beta.clone().requires_grad_(True)
+        out = tf_norm.elu_batch_norm(y1, g1, b1, mm, mv, training)
+        ref = torch.nn.functional.batch_norm(torch.nn.functional.elu(y2), mm2, mv2, g2, b2, training=training,
+                                             momentum=0.01, eps=1e-3)
+        torch.testing.assert_close(out, ref, rtol=1e-5, atol=2e-5)
+        out.backward(dout); ref.backward(dout)
+        torch.testing.assert_close(y1.grad, y2.grad, rtol=1e-4, atol=2e-5)
+        torch.testing.assert_close(g1.grad, g2.grad, rtol=1e-4, atol=1e-4 * max(1.0, float(g2.grad.abs().max())))
+        torch.testing.assert_close(b1.grad, b2.grad, rtol=1e-4, atol=1e-4 * max(1.0, float(b2.grad.abs().max())))
+        torch.testing.assert_close(mm, mm2, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(mv, mv2, rtol=1e-5, atol=1e-6)
