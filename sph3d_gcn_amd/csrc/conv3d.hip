@@ -361,22 +361,23 @@ __global__ __launch_bounds__(kBwdTWaves * 64) void dwconv_bwd_t_vec(
     }
 }
 
-// grad_filter[j] = sum over the B*nblocks partial tables, fixed order -> deterministic given the partials
+// grad_filter[j] = sum over the B*nblocks partial tables, fixed order -> deterministic given the partials.
+// 256 threads = 32 outputs x 8 partial-lanes (a one-thread-per-output loop over ~1000 slabs is latency-bound).
 __global__ __launch_bounds__(256) void reduce_filter_partials(int nparts, int total, const float* __restrict__ partial,
                                                               float* __restrict__ gradFilter)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= total) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int p = 0;
-    for (; p + 4 <= nparts; p += 4) {
-        s0 += partial[(size_t)p * total + j];
-        s1 += partial[(size_t)(p + 1) * total + j];
-        s2 += partial[(size_t)(p + 2) * total + j];
-        s3 += partial[(size_t)(p + 3) * total + j];
+    __shared__ float red[8][32];
+    const int cx = (int)threadIdx.x & 31, py = (int)threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + cx;
+    float s = 0.f;
+    if (j < total)
+        for (int p = py; p < nparts; p += 8) s += partial[(size_t)p * total + j];
+    red[py][cx] = s;
+    __syncthreads();
+    if (py == 0 && j < total) {
+        for (int k = 1; k < 8; k++) s += red[k][cx];
+        gradFilter[j] = s;
     }
-    for (; p < nparts; p++) s0 += partial[(size_t)p * total + j];
-    gradFilter[j] = (s0 + s1) + (s2 + s3);
 }
 
 // generic transposed backward (any C, r <= 256): lanes own INPUT channels c_base + lane + 64*t,
@@ -559,7 +560,7 @@ static int launch_bwd_t_vec(int B, int N, int M, int F, int C, const int* offset
     hipLaunchKernelGGL(kern, dim3(xcd_grid(B, nblocks * nslices)), dim3(kBwdTWaves * 64), lds, st, B, N, M, F, C,
                        nblocks, nslices, offsets, ent_key, ent_scale, input, filter, grad_output, grad_input, partial);
     const int total = F * CR;
-    hipLaunchKernelGGL(reduce_filter_partials, dim3((total + 255) / 256), dim3(256), 0, st, B * nblocks, total, partial,
+    hipLaunchKernelGGL(reduce_filter_partials, dim3((total + 31) / 32), dim3(256), 0, st, B * nblocks, total, partial,
                        grad_filter);
     return check_launch("sph3d_depthwise_conv3d_grad_t");
 }

@@ -218,16 +218,19 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(int M, int N, int Kd, const
 __global__ __launch_bounds__(256) void gemm_reduce_splits(int nsplit, int total, const float* __restrict__ partial,
                                                           float* __restrict__ out)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= total) return;
-    float s0 = 0.f, s1 = 0.f;
-    int p = 0;
-    for (; p + 2 <= nsplit; p += 2) {
-        s0 += partial[(size_t)p * total + j];
-        s1 += partial[(size_t)(p + 1) * total + j];
+    // 256 threads = 32 outputs x 8 split-lanes, fixed summation order (deterministic)
+    __shared__ float red[8][32];
+    const int cx = (int)threadIdx.x & 31, py = (int)threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + cx;
+    float s = 0.f;
+    if (j < total)
+        for (int p = py; p < nsplit; p += 8) s += partial[(size_t)p * total + j];
+    red[py][cx] = s;
+    __syncthreads();
+    if (py == 0 && j < total) {
+        for (int k = 1; k < 8; k++) s += red[k][cx];
+        out[j] = s;
     }
-    if (p < nsplit) s0 += partial[(size_t)p * total + j];
-    out[j] = s0 + s1;
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
@@ -322,7 +325,7 @@ extern "C" int sph3d_pointwise_gemm_tn(int R, int Cin, int Cout, const float* X,
 #undef SPH3D_TN
     if (nsplit > 1) {
         const int total = Cin * Cout;
-        hipLaunchKernelGGL(gemm_reduce_splits, dim3((total + 255) / 256), dim3(256), 0, st, nsplit, total, out, dW);
+        hipLaunchKernelGGL(gemm_reduce_splits, dim3((total + 31) / 32), dim3(256), 0, st, nsplit, total, out, dW);
     }
     return check_launch("sph3d_pointwise_gemm_tn");
 }
