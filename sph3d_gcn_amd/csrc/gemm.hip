@@ -47,48 +47,47 @@ __device__ __forceinline__ float4 load4_guard(const float* __restrict__ p, int l
 // Operand tile staging.  Whatever the memory order, the LDS image is lds[row][k] with row stride BK+4 floats:
 //   * a lane's MFMA fragment for FOUR consecutive k-steps is one aligned ds_read_b128 (see kmap below);
 //   * 16 rows x stride 20 dwords hit 16 distinct 4-dword bank slots -> the b128 reads are conflict-free;
-//   * KMAJ sources (k contiguous in memory) store with ds_write_b128, the others with 4 scalar stores.
+//   * every source is stored with ds_write_b128 (row-contiguous sources are transposed 4x4 in registers first).
 // KMAJ = true : memory is [row][k] (k contiguous);  KMAJ = false: memory is [k][row] (row contiguous).
 // BT = tile extent along the row dimension.  256 threads.
 constexpr int LDK = BK + 4;
 
 template <bool KMAJ, int BT>
 struct Stage {
-    static constexpr int NCH = (BT * BK / 4 + 255) / 256;        // float4 chunks per thread
+    // KMAJ : one float4 (4 consecutive k of one row) per chunk, BT*BK/4 chunks, stored with ds_write_b128.
+    // !KMAJ: one 4(k) x 4(row) block per unit: four float4 loads along the row dimension (lanes with the same k-quad
+    //        cover 256 contiguous bytes), transposed in registers, stored as four ds_write_b128 along k.  Lane ->
+    //        (k-quad = lane % 4, row-quad = lane / 4) puts the 8 lanes of a b128 store group on 8 distinct 16-B bank
+    //        slots.  (Round-1 PMC: the earlier scalar transposing store was 16-way bank-conflicted, 77 % of LDS cycles.)
+    static constexpr int UNITS = KMAJ ? BT * BK / 4 : BT * BK / 16;
+    static constexpr int NCH = (UNITS + 255) / 256;
+    static constexpr int NREG = KMAJ ? NCH : NCH * 4;
     static constexpr int LDS_FLOATS = BT * LDK;
-    float4 r[NCH];
+    float4 r[NREG];
 
-    // GUARD = false (every tile fully inside both matrices, 16-B aligned rows — chosen on the host): the loads carry no
-    // branch at all, stay in one basic block and are in flight during the MFMAs of the current tile.  (A run-time
-    // uniform `fast` flag was not enough: with the guarded path in the same kernel hipcc drained vmcnt before the MFMAs.)
     template <bool GUARD>
     __device__ __forceinline__ void load(const float* __restrict__ p, int ld, int row0, int k0, int rows, int kdim, bool vec_ok)
     {
-        if (!GUARD) {
-#pragma unroll
-            for (int i = 0; i < NCH; i++) {
-                const int ch = (int)threadIdx.x + i * 256;
-                if (BT * BK / 4 < 256 && ch >= BT * BK / 4) { r[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
-                if (KMAJ) {
-                    const int row = ch / (BK / 4), kq = ch % (BK / 4);
-                    r[i] = *reinterpret_cast<const float4*>(p + (size_t)(row0 + row) * ld + k0 + kq * 4);
-                } else {
-                    const int k = ch / (BT / 4), rq = ch % (BT / 4);
-                    r[i] = *reinterpret_cast<const float4*>(p + (size_t)(k0 + k) * ld + row0 + rq * 4);
-                }
-            }
-            return;
-        }
 #pragma unroll
         for (int i = 0; i < NCH; i++) {
-            const int ch = (int)threadIdx.x + i * 256;
-            if (BT * BK / 4 < 256 && ch >= BT * BK / 4) { r[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+            const int u = (int)threadIdx.x + i * 256;
             if (KMAJ) {
-                const int row = ch / (BK / 4), kq = ch % (BK / 4);
-                r[i] = load4_guard(p, ld, row0 + row, k0 + kq * 4, rows, kdim, vec_ok);
+                if (UNITS < 256 && u >= UNITS) { r[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+                const int row = u / (BK / 4), kq = u % (BK / 4);
+                if (!GUARD) r[i] = *reinterpret_cast<const float4*>(p + (size_t)(row0 + row) * ld + k0 + kq * 4);
+                else r[i] = load4_guard(p, ld, row0 + row, k0 + kq * 4, rows, kdim, vec_ok);
             } else {
-                const int k = ch / (BT / 4), rq = ch % (BT / 4);
-                r[i] = load4_guard(p, ld, k0 + k, row0 + rq * 4, kdim, rows, vec_ok);
+                if (UNITS % 256 != 0 && u >= UNITS) {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) r[i * 4 + t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    continue;
+                }
+                const int kq = u % (BK / 4), rq = u / (BK / 4);
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if (!GUARD) r[i * 4 + t] = *reinterpret_cast<const float4*>(p + (size_t)(k0 + kq * 4 + t) * ld + row0 + rq * 4);
+                    else r[i * 4 + t] = load4_guard(p, ld, k0 + kq * 4 + t, row0 + rq * 4, kdim, rows, vec_ok);
+                }
             }
         }
     }
@@ -96,15 +95,20 @@ struct Stage {
     {
 #pragma unroll
         for (int i = 0; i < NCH; i++) {
-            const int ch = (int)threadIdx.x + i * 256;
-            if (BT * BK / 4 < 256 && ch >= BT * BK / 4) continue;
+            const int u = (int)threadIdx.x + i * 256;
             if (KMAJ) {
-                const int row = ch / (BK / 4), kq = ch % (BK / 4);
+                if (UNITS < 256 && u >= UNITS) continue;
+                const int row = u / (BK / 4), kq = u % (BK / 4);
                 *reinterpret_cast<float4*>(lds + row * LDK + kq * 4) = r[i];
             } else {
-                const int k = ch / (BT / 4), rq = ch % (BT / 4);
-                float* d = lds + (rq * 4) * LDK + k;
-                d[0] = r[i].x; d[LDK] = r[i].y; d[2 * LDK] = r[i].z; d[3 * LDK] = r[i].w;
+                if (UNITS % 256 != 0 && u >= UNITS) continue;
+                const int kq = u % (BK / 4), rq = u / (BK / 4);
+                const float4 a = r[i * 4], b = r[i * 4 + 1], c = r[i * 4 + 2], d = r[i * 4 + 3];   // k = 4kq + 0..3
+                float* base = lds + (rq * 4) * LDK + kq * 4;
+                *reinterpret_cast<float4*>(base) = make_float4(a.x, b.x, c.x, d.x);
+                *reinterpret_cast<float4*>(base + LDK) = make_float4(a.y, b.y, c.y, d.y);
+                *reinterpret_cast<float4*>(base + 2 * LDK) = make_float4(a.z, b.z, c.z, d.z);
+                *reinterpret_cast<float4*>(base + 3 * LDK) = make_float4(a.w, b.w, c.w, d.w);
             }
         }
     }
@@ -196,6 +200,39 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(int M, int N, int Kd, const
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
     float* Cout = SPLITK ? Cmat + (size_t)blockIdx.y * ((size_t)M * ldc) : Cmat;
+    if (!GUARD) {
+        // whole tiles: stage each wave's 32 x WN slab through its own LDS region (the operand buffers are free after the
+        // loop's last barrier) and write it back as float4 rows: WN/4 lanes cover one row, 16 B per lane, instead of
+        // sixteen 4-byte stores per MFMA tile (the scalar epilogue was store-issue-bound: ~25 % of the kernel)
+        constexpr int EP = WN + 4;                           // padded row stride (floats)
+        static_assert(4 * 32 * EP <= 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS), "epilogue staging must fit the operand LDS");
+        float* stage = lds + wave * (32 * EP);
+        constexpr int LPR = WN / 4;                          // lanes per row
+        constexpr int RPI = 64 / LPR;                        // rows per store instruction
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const int col = wn + j * 32 + li;
+                const float bv = (!SPLITK && bias != nullptr) ? bias[n0 + col] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    float v = acc[i][j][e] + bv;
+                    if (!SPLITK && act == 1) v = v > 0.f ? v : expm1f(v);
+                    stage[((e & 3) + 8 * (e >> 2) + 4 * lk) * EP + j * 32 + li] = v;
+                }
+            }
+            // same wave wrote and reads: LDS ops of one wave complete in order, no barrier needed
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; it++) {
+                const int r = it * RPI + lane / LPR;
+                const int c4 = (lane % LPR) * 4;
+                const float4 v = *reinterpret_cast<const float4*>(&stage[r * EP + c4]);
+                *reinterpret_cast<float4*>(&Cout[(size_t)(m0 + wm + i * 32 + r) * ldc + n0 + wn + c4]) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; i++) {
 #pragma unroll
@@ -205,7 +242,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(int M, int N, int Kd, const
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-                if (!GUARD || (row < M && col < N)) {
+                if (row < M && col < N) {
                     float v = acc[i][j][e] + bv;
                     if (!SPLITK && act == 1) v = v > 0.f ? v : expm1f(v);     // ELU (alpha = 1)
                     Cout[(size_t)row * ldc + col] = v;
@@ -259,7 +296,7 @@ static int launch_gemm(int M, int N, int Kd, const float* A, int lda, const floa
 {
     // unguarded kernels need whole tiles in every variant the tile chooser may pick (128 | M, 128 | N or 64 | N, 16 | K)
     const bool whole = (M % 128 == 0) && (N % 64 == 0) && (N <= 64 || N % 128 == 0) && (Kd % BK == 0) &&
-                       (lda % 4 == 0) && (ldb % 4 == 0) && aligned16(A) && aligned16(B);
+                       (lda % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(A) && aligned16(B) && aligned16(C);
     if (whole) launch_gemm_tiles<AK, BKM, false>(M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, st);
     else launch_gemm_tiles<AK, BKM, true>(M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, st);
     return check_launch("sph3d_pointwise_gemm");
@@ -316,7 +353,7 @@ extern "C" int sph3d_pointwise_gemm_tn(int R, int Cin, int Cout, const float* X,
     }
     float* out = nsplit > 1 ? (float*)workspace : dW;
     // dW[Cin,Cout] = X^T * dY : A(m=cin, k=r) = X[r*Cin + cin] (row contiguous), B(k=r, n=cout) = dY[r*Cout + cout]
-    const bool whole = (Cin % 128 == 0) && (Cout % bn == 0) && (R % kchunk == 0) && aligned16(X) && aligned16(dY);
+    const bool whole = (Cin % 128 == 0) && (Cout % bn == 0) && (R % kchunk == 0) && aligned16(X) && aligned16(dY) && aligned16(out);
 #define SPH3D_TN(BNN, G)                                                                                                   \
     hipLaunchKernelGGL((gemm_f32_mfma<false, false, 128, BNN, true, G>), dim3(tiles, nsplit), dim3(256), 0, st, Cin, Cout, R, X, \
                        Cin, dY, Cout, out, Cout, nullptr, 0, kchunk)
