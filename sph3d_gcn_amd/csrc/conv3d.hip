@@ -23,7 +23,6 @@
 //   * Numerics: sum_k in*filt in fp32 FMA order k = 0..cnt-1, one division by cnt at the end (the
 //     reference divides every term); agreement with the oracle is ~1e-7 relative, bound 1e-5.
 #include "common.hpp"
-#include <stdlib.h>
 
 namespace sph3d {
 
@@ -72,7 +71,9 @@ __global__ __launch_bounds__(256) void dwconv_fwd_vec(
     const float* inb = input + (size_t)b * N * C;
 
     for (int mi = m_begin + wave; mi < m_end; mi += 4) {
-        const int m = order ? uniform(order[(size_t)b * M + mi]) : mi;    // optional processing order
+        // optional processing order: measured in round 1 (Morton order of the output points): no gain, the rows
+        // come from L2 either way (profiles/); kept as a hook for the LDS-tiled variant
+        const int m = order ? uniform(order[(size_t)b * M + mi]) : mi;
         const size_t row = (size_t)b * M + m;
         const int cnt = uniform(nnCount[row]);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -451,9 +452,6 @@ static int conv_dims_ok(int B, int N, int M, int F, int C, int r, int K, const c
 
 using namespace sph3d;
 
-static const int* g_order = nullptr;
-extern "C" void sph3d_debug_order(const int* o) { g_order = o; }
-
 extern "C" int sph3d_depthwise_conv3d(int B, int N, int M, int F, int C, int r, int K,
                                       const int* nn_index, const int* nn_count, const int* bin_index,
                                       const float* input, const float* filter, float* output,
@@ -479,11 +477,11 @@ extern "C" int sph3d_depthwise_conv3d(int B, int N, int M, int F, int C, int r, 
     if (vec && r == 2) {
         SPH3D_BIG_LDS(dwconv_fwd_vec<2>)
         hipLaunchKernelGGL(dwconv_fwd_vec<2>, grid, dim3(256), lds, st, B, N, M, F, C, K, mblocks, nslices,
-                           nn_index, nn_count, bin_index, input, filter, output, g_order);
+                           nn_index, nn_count, bin_index, input, filter, output, nullptr);
     } else if (vec) {
         SPH3D_BIG_LDS(dwconv_fwd_vec<1>)
         hipLaunchKernelGGL(dwconv_fwd_vec<1>, grid, dim3(256), lds, st, B, N, M, F, C, K, mblocks, nslices,
-                           nn_index, nn_count, bin_index, input, filter, output, g_order);
+                           nn_index, nn_count, bin_index, input, filter, output, nullptr);
     } else {
         SPH3D_BIG_LDS(dwconv_fwd_generic)
         hipLaunchKernelGGL(dwconv_fwd_generic, grid, dim3(256), lds, st, B, N, M, F, C, r, K, mblocks, nslices,
@@ -524,8 +522,6 @@ extern "C" size_t sph3d_depthwise_conv3d_grad_workspace(int B, int N, int M, int
 static int vec_plan(int F, int CR, int r, int& V)
 {
     if (!(r == 1 || r == 2)) return 0;
-    static const int forced = getenv("SPH3D_BWD_V") ? atoi(getenv("SPH3D_BWD_V")) : 0;
-    if (forced == 2 && F <= 33 && CR % 2 == 0) { V = 2; return 1; }
     if (F <= 33 && CR % 4 == 0) { V = 4; return 1; }
     if (F <= 65 && CR % 2 == 0) { V = 2; return 1; }
     return 0;
@@ -589,8 +585,6 @@ extern "C" int sph3d_depthwise_conv3d_grad_t(int B, int N, int M, int F, int C, 
                                         grad_input, grad_filter, partial, st)
         if (V == 4 && r == 2) SPH3D_GO(2, 4, 33);
         if (V == 4 && r == 1) SPH3D_GO(1, 4, 33);
-        if (V == 2 && F <= 33 && r == 2) SPH3D_GO(2, 2, 33);
-        if (V == 2 && F <= 33 && r == 1) SPH3D_GO(1, 2, 33);
         if (V == 2 && r == 2) SPH3D_GO(2, 2, 65);
         SPH3D_GO(1, 2, 65);
 #undef SPH3D_GO

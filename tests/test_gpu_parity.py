@@ -444,3 +444,84 @@ def test_fused_elu_batch_norm(dev, R, C):
         torch.testing.assert_close(b1.grad, b2.grad, rtol=1e-4, atol=1e-4 * max(1.0, float(b2.grad.abs().max())))
         torch.testing.assert_close(mm, mm2, rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(mv, mv2, rtol=1e-5, atol=1e-6)
+
+
+def test_modelnet_shapes_global_conv_and_odd_channels(dev):
+    """BASELINE config #2 shapes (models/SPH3D_modelnet.py:47-93): 10000-point clouds (not a multiple of 64 / 1024),
+    odd channel counts (35, 67, 131 -> generic kernels), and the global conv: K = 156 > 64 neighbours, one query
+    (the cloud centroid), kernel [8,2,1] -> F = 17 bins."""
+    B, N = 2, 10000
+    xyz = synth.modelnet_batch(5, B, N)
+    xt = _t(xyz, dev)
+    idx_o, cnt_o, dst_o = oracle.build_sphere_neighbor(xyz, xyz, 0.1, None, 64)
+    idx, cnt, dst = tf_nnquery.build_sphere_neighbor(xt, xt, 0.1, None, 64)
+    np.testing.assert_array_equal(_n(idx), idx_o)
+    np.testing.assert_array_equal(_n(cnt), cnt_o)
+    filt_o = oracle.spherical_kernel(xyz, xyz, idx_o, cnt_o, dst_o, 0.1, [8, 2, 2])
+    filt = tf_buildkernel.spherical_kernel(xt, xt, idx, cnt, dst, 0.1, [8, 2, 2])
+    np.testing.assert_array_equal(_n(filt), filt_o)
+    fps_o = oracle.farthest_point_sample(2500, xyz)
+    np.testing.assert_array_equal(_n(tf_sample.farthest_point_sample(2500, xt)), fps_o)
+    rng = np.random.RandomState(3)
+    x = rng.randn(B, N, 35).astype(np.float32)
+    w = rng.randn(33, 35, 2).astype(np.float32)
+    go = rng.randn(B, N, 70).astype(np.float32)
+    xg = _t(x, dev).requires_grad_(True)
+    wg = _t(w, dev).requires_grad_(True)
+    out = tf_conv3d.depthwise_conv3d(xg, wg, idx, cnt, filt)
+    np.testing.assert_allclose(_n(out), oracle.depthwise_conv3d(x, w, idx_o, cnt_o, filt_o), **TOL)
+    out.backward(_t(go, dev))
+    gi_o, gf_o = oracle.depthwise_conv3d_grad(x, w, go, idx_o, cnt_o, filt_o)
+    np.testing.assert_allclose(_n(xg.grad), gi_o, **TOL)
+    s = max(1.0, float(np.abs(gf_o).max()))
+    np.testing.assert_allclose(_n(wg.grad) / s, gf_o / s, **TOL)
+    # global graph over the last level (156 points), query = centroid of the input cloud, radius 100, K = 156
+    last = xyz[np.arange(B)[:, None], fps_o[:, :156]]
+    centroid = xyz.mean(axis=1, keepdims=True).astype(np.float32)
+    gi_o_, gc_o, gd_o = oracle.build_sphere_neighbor(last, centroid, 100.0, None, 156)
+    gidx, gcnt, gdst = tf_nnquery.build_sphere_neighbor(_t(last, dev), _t(centroid, dev), 100.0, None, 156)
+    np.testing.assert_array_equal(_n(gidx), gi_o_)
+    assert (gc_o == 156).all() and np.array_equal(_n(gcnt), gc_o)
+    gf_o_ = oracle.spherical_kernel(last, centroid, gi_o_, gc_o, gd_o, 100.0, [8, 2, 1])
+    gfilt = tf_buildkernel.spherical_kernel(_t(last, dev), _t(centroid, dev), gidx, gcnt, gdst, 100.0, [8, 2, 1])
+    np.testing.assert_array_equal(_n(gfilt), gf_o_)
+    assert gf_o_.max() <= 16
+    feat = rng.randn(B, 156, 128).astype(np.float32)
+    w17 = rng.randn(17, 128, 2).astype(np.float32)
+    gog = rng.randn(B, 1, 256).astype(np.float32)
+    ft = _t(feat, dev).requires_grad_(True)
+    wt = _t(w17, dev).requires_grad_(True)
+    gout = tf_conv3d.depthwise_conv3d(ft, wt, gidx, gcnt, gfilt)
+    np.testing.assert_allclose(_n(gout), oracle.depthwise_conv3d(feat, w17, gi_o_, gc_o, gf_o_), **TOL)
+    gout.backward(_t(gog, dev))
+    a, b = oracle.depthwise_conv3d_grad(feat, w17, gog, gi_o_, gc_o, gf_o_)
+    np.testing.assert_allclose(_n(ft.grad), a, **TOL)
+    np.testing.assert_allclose(_n(wt.grad), b, **TOL)
+
+
+def test_scannet_stress_65536_points(dev):
+    """BASELINE config #5 shape (one 65 536-point cloud): the multi-chunk LDS path of the neighbour search (N > 12 288)
+    and the workspace fallback of FPS (n > 24 576).  The oracle checks a subset of queries / a short FPS prefix;
+    the full outputs are checked by properties."""
+    N, K, r = 65536, 64, 0.1
+    xyz = synth.s3dis_batch(77, 1, N, extent=(6.0, 6.0, 3.0))[0]
+    xt = _t(xyz, dev)
+    idx, cnt, dst = tf_nnquery.build_sphere_neighbor(xt, xt, r, None, K)
+    idx_n, cnt_n = _n(idx), _n(cnt)
+    assert cnt_n.min() >= 1 and cnt_n.max() <= K
+    valid = np.arange(K)[None, None, :] < cnt_n[:, :, None]
+    assert (np.diff(idx_n, axis=2)[valid[:, :, 1:]] > 0).all() and (idx_n[~valid] == 0).all()
+    # chains: query j is searched with radius r (+) 0.05 * (j // 1024); check the first 1024 queries (chain position 0)
+    # and the last 1024 (position 63, radius 3.25) against the oracle run on those queries as db-vs-query
+    i_o, c_o, d_o = oracle.build_sphere_neighbor(xyz, xyz[:, :1024], r, None, K)
+    np.testing.assert_array_equal(idx_n[:, :1024], i_o)
+    np.testing.assert_array_equal(cnt_n[:, :1024], c_o)
+    r63 = np.float32(r)
+    for _ in range(63):
+        r63 = np.float32(np.float64(r63) + 0.05)          # the chain's radius after 63 single-pass queries (3.25)
+    i_l, c_l, d_l = oracle.build_sphere_neighbor(xyz, xyz[:, -1024:], float(r63), None, K)
+    np.testing.assert_array_equal(idx_n[:, -1024:], i_l)
+    np.testing.assert_array_equal(cnt_n[:, -1024:], c_l)
+    m = 300
+    fps = _n(tf_sample.farthest_point_sample(m, xt))
+    np.testing.assert_array_equal(fps, oracle.farthest_point_sample(m, xyz))
