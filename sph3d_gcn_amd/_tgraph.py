@@ -28,12 +28,17 @@ def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1
     """-> (offsets[B*(n_src*F+1)] i32, ent_key[B*M*K] i32, ent_scale[B*M*K] f32) on nn_index's device;
     F = num_bins (the filter's bin count when bin_index is given, else 1)"""
     F = int(num_bins) if bin_index is not None else 1
-    key = (_ident(nn_index), _ident(nn_count), _ident(bin_index), _ident(weight), int(n_src), F, tuple(nn_index.shape),
-           torch.cuda.current_stream().cuda_stream)
+    key = (_ident(nn_index), _ident(nn_count), _ident(bin_index), _ident(weight), int(n_src), F, tuple(nn_index.shape))
+    cur = torch.cuda.current_stream()
     hit = _cache.get(key)
     if hit is not None:
         _cache.move_to_end(key)
-        return hit[0]
+        out, _keep, ev, built_on = hit
+        if built_on != cur.cuda_stream:          # built ahead of time on the graph stream: order this stream after it
+            cur.wait_event(ev)
+            for t in out:
+                t.record_stream(cur)
+        return out
     B, M, K = nn_index.shape
     dev = nn_index.device
     offsets = torch.empty((B * (n_src * F + 1),), dtype=torch.int32, device=dev)
@@ -46,7 +51,9 @@ def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1
                                        _lib.ptr(weight), _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale),
                                        _lib.ptr(ws), wsb, _lib.stream_ptr()))
     out = (offsets, ent_key, ent_scale)
-    _cache[key] = (out, (nn_index, nn_count, bin_index, weight))
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    _cache[key] = (out, (nn_index, nn_count, bin_index, weight), ev, cur.cuda_stream)
     while len(_cache) > _MAX_ENTRIES:
         _cache.popitem(last=False)
     return out

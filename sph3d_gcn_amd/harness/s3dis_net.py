@@ -74,12 +74,15 @@ _side_stream = {}
 
 
 class GraphPlan:
-    """All graph-construction ops of one forward (they depend on xyz only), built lazily level by
-    level.  Same ops, arguments and results as the build_graph / build_graph_deconv / spherical_kernel calls of
-    models/SPH3D_s3dis.py:53-98; only the ISSUE ORDER differs: FPS is m strictly sequential rounds on one
-    workgroup per cloud (16 of 256 CUs busy), so on the GPU the whole sampling chain is launched up front on a
-    side HIP stream and overlaps the level-0 neighbour search, kernel binning and convolutions, which need only
-    the input xyz; the main stream waits (per level) only where sampled coordinates are first needed."""
+    """All graph-construction ops of one forward (they depend on xyz only).  Same ops, arguments and
+    results as the build_graph / build_graph_deconv / spherical_kernel calls of models/SPH3D_s3dis.py:53-98; only
+    the ISSUE ORDER and the STREAMS differ.  On the GPU three HIP streams run concurrently:
+      * sampling stream: the FPS chain — m strictly sequential rounds on one workgroup per cloud (16 of 256 CUs);
+      * graph stream   : every neighbour search, kernel binning, pooled-row gather and (for the backward pass) the
+                         transposed graphs, level by level — VALU / integer-atomic bound work;
+      * main stream    : the feature path (convolutions, GEMMs, normalisation) — L2 / MFMA / HBM bound work,
+    and the main stream waits, per level, only on the event of the graph it is about to use.
+    On CPU tensors (oracle-backed tests) everything is built lazily on the spot."""
 
     def __init__(self, points, config, overlap=True):
         self.config = config
@@ -87,17 +90,23 @@ class GraphPlan:
         self.use_side = bool(overlap and xyz.is_cuda)
         self.xyz_layers, self.indices, self.events = [xyz], [], []
         self._enc, self._dec = {}, {}
+        self._enc_ev, self._dec_ev, self._pool_ev = {}, {}, {}
+        self._synced = set()
         if self.use_side:
             self.main = torch.cuda.current_stream()
-            side = _side_stream.get(xyz.device)
-            if side is None:
-                side = _side_stream[xyz.device] = torch.cuda.Stream(device=xyz.device)
-            side.wait_stream(self.main)
-            with torch.cuda.stream(side):
-                self._sampling_chain(side)
+            streams = _side_stream.get(xyz.device)
+            if streams is None:
+                streams = _side_stream[xyz.device] = (torch.cuda.Stream(device=xyz.device),
+                                                      torch.cuda.Stream(device=xyz.device))
+            s_fps, s_graph = streams
+            s_fps.wait_stream(self.main)
+            s_graph.wait_stream(self.main)
+            with torch.cuda.stream(s_fps):
+                self._sampling_chain(s_fps)
+            with torch.cuda.stream(s_graph):
+                self._build_all(s_graph)
         else:
             self._sampling_chain(None)
-        self._waited = 0          # number of sampling levels the main stream has synchronised with
 
     def _sampling_chain(self, side):
         """FPS level after level (each level samples the previous level's samples)."""
@@ -124,52 +133,93 @@ class GraphPlan:
                 ev.record(side)
                 self.events.append(ev)
 
-    def _need_sampling(self, levels):
-        """main stream may use the results of sampling levels < `levels`"""
-        if not self.use_side:
+    # ---- graph construction proper (called on the graph stream, or lazily on CPU) ----
+    def _make_enc(self, l):
+        c = self.config
+        xyz = self.xyz_layers[l]
+        idx, cnt, dst = s3g_util.neighbor_fn(xyz, xyz, radius=c.radius[l], nnsample=c.nn_uplimit[l])      # util.py:29
+        filt = s3g_util.spherical_kernel(xyz, xyz, idx, cnt, dst, c.radius[l], kernel=c.kernel)
+        return dict(intra_idx=idx, intra_cnt=cnt, filt_idx=filt)
+
+    def _make_pool(self, l, g):
+        g["inter_idx"] = s3g_util.gather_nd(g["intra_idx"], self.indices[l])       # models/SPH3D_s3dis.py:68-72
+        g["inter_cnt"] = s3g_util.gather_nd(g["intra_cnt"], self.indices[l])
+
+    def _make_dec(self, l):
+        c = self.config
+        L = len(c.radius)
+        radius, uplimit = c.radius[L - 1 - l], c.nn_uplimit[L - 1 - l]
+        xyz_rev = list(reversed(self.xyz_layers))
+        xyz_c, xyz_unpool = xyz_rev[l], xyz_rev[l + 1]
+        intra_idx, intra_cnt, intra_dst, inter_idx, inter_cnt, inter_dst = s3g_util.build_graph_deconv(
+            xyz_c, xyz_unpool, radius, uplimit)
+        filt_idx = s3g_util.spherical_kernel(xyz_c, xyz_c, intra_idx, intra_cnt, intra_dst, radius, kernel=c.kernel)
+        return dict(intra_idx=intra_idx, intra_cnt=intra_cnt, filt_idx=filt_idx, inter_idx=inter_idx,
+                    inter_cnt=inter_cnt, inter_dst=inter_dst)
+
+    def _pretranspose(self, g, n_src_conv, n_src_unpool=None):
+        """build the transposed graphs the backward pass will ask for (cached in _tgraph), off the critical path"""
+        from .. import _tgraph
+        _tgraph.transpose(g["intra_idx"], g["intra_cnt"], n_src_conv, bin_index=g["filt_idx"],
+                          num_bins=self.config.binSize)
+        if n_src_unpool is not None and self.config.unpool_method == 'mean':
+            _tgraph.transpose(g["inter_idx"], g["inter_cnt"], n_src_unpool)
+
+    def _build_all(self, stream):
+        c = self.config
+        L = len(c.radius)
+        for l in range(L):
+            if l >= 1:
+                stream.wait_event(self.events[l - 1])            # sampled coordinates of level l
+            g = self._make_enc(l)
+            self._pretranspose(g, self.xyz_layers[l].shape[1])
+            self._enc[l] = g
+            ev = torch.cuda.Event(); ev.record(stream); self._enc_ev[l] = ev
+        for l in range(L):
+            if c.num_sample[l] > 1:
+                stream.wait_event(self.events[l])
+                self._make_pool(l, self._enc[l])
+                ev = torch.cuda.Event(); ev.record(stream); self._pool_ev[l] = ev
+        stream.wait_event(self.events[L - 1])
+        xyz_rev = list(reversed(self.xyz_layers))
+        for l in range(L):
+            g = self._make_dec(l)
+            self._pretranspose(g, xyz_rev[l].shape[1], n_src_unpool=xyz_rev[l].shape[1])
+            self._dec[l] = g
+            ev = torch.cuda.Event(); ev.record(stream); self._dec_ev[l] = ev
+
+    def _sync(self, key, ev, tensors):
+        if key in self._synced:
             return
-        while self._waited < levels:
-            l = self._waited
-            self.main.wait_event(self.events[l])
-            if self.indices[l] is not None:
-                self.indices[l].record_stream(self.main)
-                self.xyz_layers[l + 1].record_stream(self.main)
-            self._waited += 1
+        self.main.wait_event(ev)
+        for t in tensors:
+            if torch.is_tensor(t):
+                t.record_stream(self.main)
+        self._synced.add(key)
 
     def enc(self, l):
-        """encoder level l: intra graph + bins of xyz_l (needs sampling levels < l)"""
-        if l not in self._enc:
-            c = self.config
-            self._need_sampling(l)
-            xyz = self.xyz_layers[l]
-            idx, cnt, dst = s3g_util.neighbor_fn(xyz, xyz, radius=c.radius[l], nnsample=c.nn_uplimit[l])  # util.py:29
-            filt = s3g_util.spherical_kernel(xyz, xyz, idx, cnt, dst, c.radius[l], kernel=c.kernel)
-            self._enc[l] = dict(intra_idx=idx, intra_cnt=cnt, filt_idx=filt)
+        """encoder level l: intra graph + bins of xyz_l"""
+        if self.use_side:
+            self._sync(("enc", l), self._enc_ev[l], [self._enc[l]["intra_idx"], self._enc[l]["intra_cnt"],
+                                                     self._enc[l]["filt_idx"], self.xyz_layers[l]])
+        elif l not in self._enc:
+            self._enc[l] = self._make_enc(l)
         return self._enc[l]
 
     def pool(self, l):
-        """rows of the level-l intra graph at the sampled points (models/SPH3D_s3dis.py:68-72)"""
+        """rows of the level-l intra graph at the sampled points"""
         g = self.enc(l)
-        if "inter_idx" not in g:
-            self._need_sampling(l + 1)
-            g["inter_idx"] = s3g_util.gather_nd(g["intra_idx"], self.indices[l])
-            g["inter_cnt"] = s3g_util.gather_nd(g["intra_cnt"], self.indices[l])
+        if self.use_side:
+            self._sync(("pool", l), self._pool_ev[l], [g["inter_idx"], g["inter_cnt"]])
+        elif "inter_idx" not in g:
+            self._make_pool(l, g)
         return g
 
     def dec(self, l):
-        if l not in self._dec:
-            c = self.config
-            L = len(c.radius)
-            self._need_sampling(L)
-            radius, uplimit = c.radius[L - 1 - l], c.nn_uplimit[L - 1 - l]
-            xyz_rev = list(reversed(self.xyz_layers))
-            xyz_c, xyz_unpool = xyz_rev[l], xyz_rev[l + 1]
-            intra_idx, intra_cnt, intra_dst, inter_idx, inter_cnt, inter_dst = s3g_util.build_graph_deconv(
-                xyz_c, xyz_unpool, radius, uplimit)
-            filt_idx = s3g_util.spherical_kernel(xyz_c, xyz_c, intra_idx, intra_cnt, intra_dst, radius,
-                                                 kernel=c.kernel)
-            self._dec[l] = dict(intra_idx=intra_idx, intra_cnt=intra_cnt, filt_idx=filt_idx, inter_idx=inter_idx,
-                                inter_cnt=inter_cnt, inter_dst=inter_dst)
+        if self.use_side:
+            self._sync(("dec", l), self._dec_ev[l], list(self._dec[l].values()))
+        elif l not in self._dec:
+            self._dec[l] = self._make_dec(l)
         return self._dec[l]
 
 
