@@ -10,7 +10,8 @@
 //
 // MI355X design: v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain, no TF32-style truncation, so the
 // 1e-5 activation bound holds).  Workgroup = 4 waves, block tile 128x128 / 128x64 / 64x64 (the largest that still
-// gives all 256 CUs work: the row count shrinks 64-fold from level 0 to level 3), BK = 16; each wave owns a quarter
+// gives all 256 CUs work: the row count shrinks 64-fold from level 0 to level 3), BK = 32 when the grid has >= 3
+// workgroups per CU (half the barriers) else 16 (more resident workgroups); each wave owns a quarter
 // of the tile as independent 32x32 accumulators.  Operand tiles go global -> registers (prefetch of tile t+1 during
 // the MFMAs of tile t) -> a double-buffered LDS image lds[row][k] (one barrier per k-tile) from which a lane's
 // operands for four MFMA steps are a single conflict-free ds_read_b128 (Stage / kmap comments below).
@@ -24,7 +25,8 @@ namespace sph3d {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128;
-constexpr int BK = 16;
+constexpr int BKS = 16;      // k-tile for small grids (more workgroups per CU)
+constexpr int BKL = 32;      // k-tile for large grids (half the barriers)
 
 // load a 4-wide chunk of a [rows x cols] row-major matrix at (r, c..c+3), zero outside
 __device__ __forceinline__ float4 load4_guard(const float* __restrict__ p, int ld, int r, int c, int rows, int cols, bool vec_ok)
@@ -50,10 +52,9 @@ __device__ __forceinline__ float4 load4_guard(const float* __restrict__ p, int l
 //   * every source is stored with ds_write_b128 (row-contiguous sources are transposed 4x4 in registers first).
 // KMAJ = true : memory is [row][k] (k contiguous);  KMAJ = false: memory is [k][row] (row contiguous).
 // BT = tile extent along the row dimension.  256 threads.
-constexpr int LDK = BK + 4;
-
-template <bool KMAJ, int BT>
+template <bool KMAJ, int BT, int BK>
 struct Stage {
+    static constexpr int LDK = BK + 4;
     // KMAJ : one float4 (4 consecutive k of one row) per chunk, BT*BK/4 chunks, stored with ds_write_b128.
     // !KMAJ: one 4(k) x 4(row) block per unit: four float4 loads along the row dimension (lanes with the same k-quad
     //        cover 256 contiguous bytes), transposed in registers, stored as four ds_write_b128 along k.  Lane ->
@@ -120,13 +121,14 @@ struct Stage {
 //
 // C[M,N] = A * B for one BMT x BN tile and the k range [k_begin, k_end).
 // A(m,k): AK ? A[m*lda + k] : A[k*lda + m].   B(k,n): BKM ? B[n*ldb + k] : B[k*ldb + n].
-template <bool AK, bool BKM, int BMT, int BN, bool SPLITK, bool GUARD>
+template <bool AK, bool BKM, int BMT, int BN, int BK, bool SPLITK, bool GUARD>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(int M, int N, int Kd, const float* __restrict__ A, int lda,
                                                      const float* __restrict__ B, int ldb, float* __restrict__ Cmat,
                                                      int ldc, const float* __restrict__ bias, int act, int kchunk)
 {
-    using SA = Stage<AK, BMT>;
-    using SB = Stage<BKM, BN>;
+    using SA = Stage<AK, BMT, BK>;
+    using SB = Stage<BKM, BN, BK>;
+    constexpr int LDK = BK + 4;
     __shared__ __attribute__((aligned(16))) float lds[2 * (SA::LDS_FLOATS + SB::LDS_FLOATS)];
     constexpr int WM = BMT / 2, WN = BN / 2;     // wave sub-tile
     constexpr int TM = WM / 32, TN = WN / 32;    // MFMA tiles per wave
@@ -278,14 +280,19 @@ static void launch_gemm_tiles(int M, int N, int Kd, const float* A, int lda, con
 {
     // tile choice: the largest tile that still gives every CU a workgroup
     auto ntiles = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-    if (N > 64 && ntiles(128, 128) >= 256) {
-        hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 128, false, GUARD>), dim3((unsigned)ntiles(128, 128)), dim3(256), 0, st,
+    if (N > 64 && ntiles(128, 128) >= 768 && Kd % BKL == 0) {        // >= 3 workgroups per CU: the wide k-tile pays
+        constexpr int BKX = BKL;
+        hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 128, BKX, false, GUARD>), dim3((unsigned)ntiles(128, 128)), dim3(256), 0, st,
+                           M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
+    } else if (N > 64 && ntiles(128, 128) >= 256) {
+        constexpr int BKX = BKS;
+        hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 128, BKX, false, GUARD>), dim3((unsigned)ntiles(128, 128)), dim3(256), 0, st,
                            M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
     } else if (ntiles(128, 64) >= 256) {
-        hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 64, false, GUARD>), dim3((unsigned)ntiles(128, 64)), dim3(256), 0, st,
+        hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 64, BKS, false, GUARD>), dim3((unsigned)ntiles(128, 64)), dim3(256), 0, st,
                            M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
     } else {
-        hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 64, 64, false, GUARD>), dim3((unsigned)ntiles(64, 64)), dim3(256), 0, st, M,
+        hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 64, 64, BKS, false, GUARD>), dim3((unsigned)ntiles(64, 64)), dim3(256), 0, st, M,
                            N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
     }
 }
@@ -295,7 +302,7 @@ static int launch_gemm(int M, int N, int Kd, const float* A, int lda, const floa
                        const float* bias, int act, hipStream_t st)
 {
     // unguarded kernels need whole tiles in every variant the tile chooser may pick (128 | M, 128 | N or 64 | N, 16 | K)
-    const bool whole = (M % 128 == 0) && (N % 64 == 0) && (N <= 64 || N % 128 == 0) && (Kd % BK == 0) &&
+    const bool whole = (M % 128 == 0) && (N % 64 == 0) && (N <= 64 || N % 128 == 0) && (Kd % BKS == 0) &&
                        (lda % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(A) && aligned16(B) && aligned16(C);
     if (whole) launch_gemm_tiles<AK, BKM, false>(M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, st);
     else launch_gemm_tiles<AK, BKM, true>(M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, st);
@@ -305,6 +312,7 @@ static int launch_gemm(int M, int N, int Kd, const float* A, int lda, const floa
 // split-K plan for the weight gradient: enough (tile, split) workgroups to fill 256 CUs, k chunks multiple of BK
 static void tn_plan(int R, int Cin, int Cout, int& bn, int& tiles, int& nsplit, int& kchunk)
 {
+    // the weight gradient always has thousands of (tile, split) workgroups: wide k-tile
     bn = Cout > 64 ? 128 : 64;
     tiles = ((Cin + BM - 1) / BM) * ((Cout + bn - 1) / bn);
     int want = (1024 + tiles - 1) / tiles;            // ~4 workgroups per CU in total
@@ -312,7 +320,7 @@ static void tn_plan(int R, int Cin, int Cout, int& bn, int& tiles, int& nsplit, 
     nsplit = want < maxsplit ? want : maxsplit;
     if (nsplit < 1) nsplit = 1;
     kchunk = (R + nsplit - 1) / nsplit;
-    kchunk = ((kchunk + BK - 1) / BK) * BK;
+    kchunk = ((kchunk + BKL - 1) / BKL) * BKL;
     nsplit = (R + kchunk - 1) / kchunk;
 }
 
@@ -355,7 +363,7 @@ extern "C" int sph3d_pointwise_gemm_tn(int R, int Cin, int Cout, const float* X,
     // dW[Cin,Cout] = X^T * dY : A(m=cin, k=r) = X[r*Cin + cin] (row contiguous), B(k=r, n=cout) = dY[r*Cout + cout]
     const bool whole = (Cin % 128 == 0) && (Cout % bn == 0) && (R % kchunk == 0) && aligned16(X) && aligned16(dY) && aligned16(out);
 #define SPH3D_TN(BNN, G)                                                                                                   \
-    hipLaunchKernelGGL((gemm_f32_mfma<false, false, 128, BNN, true, G>), dim3(tiles, nsplit), dim3(256), 0, st, Cin, Cout, R, X, \
+    hipLaunchKernelGGL((gemm_f32_mfma<false, false, 128, BNN, BKL, true, G>), dim3(tiles, nsplit), dim3(256), 0, st, Cin, Cout, R, X, \
                        Cin, dY, Cout, out, Cout, nullptr, 0, kchunk)
     if (bn == 128) { if (whole) SPH3D_TN(128, false); else SPH3D_TN(128, true); }
     else { if (whole) SPH3D_TN(64, false); else SPH3D_TN(64, true); }

@@ -1,0 +1,17 @@
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from sph3d_gcn_amd import _lib, tf_gemm
+from sph3d_gcn_amd.harness import s3dis_net, synth, dist as hdist
+dev=torch.device('cuda:0'); _lib.lib()
+pts,label,inner=bench.make_batch(0,dev)
+model=s3dis_net.SPH3DS3DIS(s3dis_net.s3dis_config(8192),device=dev)
+pred,_=model(pts,True); model.loss(pred,label,inner).backward()
+flat=hdist.FlatGradAllReduce(model.parameters()); opt=torch.optim.Adam([flat.flat_param],lr=1e-3,eps=1e-4)
+for _ in range(3): bench.train_step(model,flat,opt,pts,label,inner)
+torch.cuda.synchronize()
+t0=time.perf_counter()
+for _ in range(5): bench.train_step(model,flat,opt,pts,label,inner)
+t1=time.perf_counter(); torch.cuda.synchronize(); t2=time.perf_counter()
+print("issue ms/step %.2f   total ms/step %.2f"%((t1-t0)/5*1e3,(t2-t0)/5*1e3))
