@@ -221,7 +221,7 @@ constexpr int kBwdTWaves = 4;
 constexpr int kBwdTPointsPerWG = 128;
 
 template <int R, int V, int MAXF>
-__global__ __launch_bounds__(kBwdTWaves * 64) void dwconv_bwd_t_vec(
+__global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
     int B, int N, int M, int F, int C, int nblocks, int nslices,
     const int* __restrict__ offsets, const int* __restrict__ entKey, const float* __restrict__ entScale,
     const float* __restrict__ input, const float* __restrict__ filter, const float* __restrict__ gradOutput,
