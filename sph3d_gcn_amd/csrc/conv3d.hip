@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_generic(
 // any is used (memory-level parallelism; the kernel is latency-bound at 2 waves/SIMD otherwise).
 // ------------------------------------------------------------------------------------------
 constexpr int kBwdTWaves = 4;
-constexpr int kBwdTPointsPerWG = 128;
+constexpr int kBwdTPointsPerWG = 64;     // measured: 256 -> 1.90 ms, 128 -> 1.15, 64 -> 0.90, 32 -> 0.91, 16 -> 1.22 (tail / balance vs per-block setup)
 
 template <int R, int V, int MAXF>
 __global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
