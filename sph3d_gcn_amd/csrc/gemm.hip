@@ -278,17 +278,18 @@ template <bool AK, bool BKM, bool GUARD>
 static void launch_gemm_tiles(int M, int N, int Kd, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                               const float* bias, int act, hipStream_t st)
 {
-    // tile choice: the largest tile that still gives every CU a workgroup
+    // tile choice: the largest tile that still gives every CU TWO workgroups (measured: with >= 256 tiles as the rule the
+    // mid-size levels ran 50 TF, with >= 512 they run 80-90 TF: one partial wave of workgroups leaves half the CUs idle)
     auto ntiles = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     if (N > 64 && ntiles(128, 128) >= 768 && Kd % BKL == 0) {        // >= 3 workgroups per CU: the wide k-tile pays
         constexpr int BKX = BKL;
         hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 128, BKX, false, GUARD>), dim3((unsigned)ntiles(128, 128)), dim3(256), 0, st,
                            M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
-    } else if (N > 64 && ntiles(128, 128) >= 256) {
+    } else if (N > 64 && ntiles(128, 128) >= 512) {
         constexpr int BKX = BKS;
         hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 128, BKX, false, GUARD>), dim3((unsigned)ntiles(128, 128)), dim3(256), 0, st,
                            M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
-    } else if (ntiles(128, 64) >= 256) {
+    } else if (ntiles(128, 64) >= 512) {
         hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 64, BKS, false, GUARD>), dim3((unsigned)ntiles(128, 64)), dim3(256), 0, st,
                            M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
     } else {
