@@ -304,7 +304,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("%s%s" % (name, list(ints[:7])))
+                table = json.load(open(tpath))
+                traffic = table.get("%s%s" % (name, list(ints[:7])), table.get("%s%s" % (name, list(ints[:6]))))
             except Exception:
                 traffic = None
         roofline = {"kernel": name, "dims": list(ints[:7]), "bound": bound, "achieved": round(achieved, 1),
