@@ -121,8 +121,10 @@ struct Stage {
 //
 // C[M,N] = A * B for one BMT x BN tile and the k range [k_begin, k_end).
 // A(m,k): AK ? A[m*lda + k] : A[k*lda + m].   B(k,n): BKM ? B[n*ldb + k] : B[k*ldb + n].
+// 128x128 / BK = 16 unguarded tiles: 124 VGPRs and 40 KB of LDS -> FOUR workgroups per CU, so the common grids of
+// 1024 / 2048 tiles have no partial last wave of workgroups (3 per CU left a quarter of the run at 1/3 occupancy).
 template <bool AK, bool BKM, int BMT, int BN, int BK, bool SPLITK, bool GUARD>
-__global__ __launch_bounds__(256) void gemm_f32_mfma(int M, int N, int Kd, const float* __restrict__ A, int lda,
+__global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? 4 : 2) void gemm_f32_mfma(int M, int N, int Kd, const float* __restrict__ A, int lda,
                                                      const float* __restrict__ B, int ldb, float* __restrict__ Cmat,
                                                      int ldc, const float* __restrict__ bias, int act, int kchunk)
 {
@@ -281,7 +283,7 @@ static void launch_gemm_tiles(int M, int N, int Kd, const float* A, int lda, con
     // tile choice: the largest tile that still gives every CU TWO workgroups (measured: with >= 256 tiles as the rule the
     // mid-size levels ran 50 TF, with >= 512 they run 80-90 TF: one partial wave of workgroups leaves half the CUs idle)
     auto ntiles = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-    if (N > 64 && ntiles(128, 128) >= 768 && Kd % BKL == 0) {        // >= 3 workgroups per CU: the wide k-tile pays
+    if (false) {        // (BK = 32 for the big grids was measured equal or slower than BK = 16 at 4 workgroups per CU)
         constexpr int BKX = BKL;
         hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 128, BKX, false, GUARD>), dim3((unsigned)ntiles(128, 128)), dim3(256), 0, st,
                            M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
