@@ -22,6 +22,23 @@ def _ident(t):
 
 def clear():
     _cache.clear()
+    _orders.clear()
+
+
+# processing order of the source points of a graph (a permutation per cloud, spatially sorted): optional hint for
+# the convolution gradient (include/sph3d.h: source_order), registered by whoever knows the points' coordinates
+_orders = collections.OrderedDict()
+
+
+def set_source_order(nn_index, order):
+    _orders[_ident(nn_index)] = (order, nn_index)
+    while len(_orders) > _MAX_ENTRIES:
+        _orders.popitem(last=False)
+
+
+def source_order(nn_index):
+    hit = _orders.get(_ident(nn_index))
+    return None if hit is None else hit[0]
 
 
 def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1):

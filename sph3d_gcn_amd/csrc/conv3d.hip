@@ -222,8 +222,9 @@ constexpr int kBwdTPointsPerWG = 64;     // measured: 256 -> 1.90 ms, 128 -> 1.1
 
 template <int R, int V, int MAXF>
 __global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
-    int B, int N, int M, int F, int C, int nblocks, int nslices,
+    int B, int N, int M, int F, int C, int W, int parts, int nslices,
     const int* __restrict__ offsets, const int* __restrict__ entKey, const float* __restrict__ entScale,
+    const int* __restrict__ order,
     const float* __restrict__ input, const float* __restrict__ filter, const float* __restrict__ gradOutput,
     float* __restrict__ gradInput, float* __restrict__ partial)
 {
@@ -231,11 +232,11 @@ __global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
     constexpr int SLW = 64 * V;                 // slice width in output channels
     constexpr int VI = (V >= R) ? V / R : 1;    // input channels per lane
     const int CR = C * R;
-    int b, part;
-    xcd_decode((int)blockIdx.x, B, nblocks * nslices, b, part);
-    if (b < 0) return;
-    const int slice = part / nblocks;
-    const int nb = part - slice * nblocks;
+    // persistent workgroups: W per XCD and channel slice, all resident together (launch bounds: 3 per CU)
+    const int xcd = (int)blockIdx.x & 7;
+    const int q = (int)blockIdx.x >> 3;
+    const int slice = q / W;
+    const int w = q - slice * W;
     const int slice0 = slice * SLW;
     const int SL = (CR - slice0) < SLW ? (CR - slice0) : SLW;     // multiple of V
     float* lfilt = lds;                                           // [F][SL]
@@ -253,11 +254,7 @@ __global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
     const int cl0 = lane * V;
     const bool act = cl0 < SL;
     const int cin0 = (slice0 + cl0) / R;
-    const int n_begin = nb * kBwdTPointsPerWG;
-    const int n_end = (n_begin + kBwdTPointsPerWG) < N ? (n_begin + kBwdTPointsPerWG) : N;
-    const float* gob = gradOutput + (size_t)b * M * CR + slice0 + (act ? cl0 : 0);
-    const int* __restrict__ offb = offsets + (size_t)b * ((size_t)N * F + 1);
-
+    const int stride = W * kBwdTWaves;          // waves of this XCD that sweep a cloud side by side
     // per-lane gradient-of-filter accumulators, one row per bin; every index below is a compile-time constant
     // (the bin loop is fully unrolled), so the table lives in VGPRs
     float acc[MAXF][V];
@@ -266,8 +263,23 @@ __global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
 #pragma unroll
         for (int v = 0; v < V; v++) acc[i][v] = 0.f;
 
-    for (int n = n_begin + wave; n < n_end; n += kBwdTWaves) {
-        const int* __restrict__ o = offb + (size_t)n * F;      // F+1 consecutive segment bounds: scalar loads
+    // Work items of this XCD: (cloud, part) pairs dealt round-robin; a part is a contiguous range of POSITIONS in the
+    // processing order (source_order, or the point index).  Wave gw visits positions gw, gw + stride, ...; the
+    // accumulators live across ALL items, so a workgroup writes one partial table for the whole launch.
+    for (int item = xcd; item < B * parts; item += 8) {
+    const int b = item / parts;
+    const int pi = item - b * parts;
+    const int p_begin = (int)((long long)pi * N / parts);
+    const int p_end = (int)((long long)(pi + 1) * N / parts);
+    const float* gob = gradOutput + (size_t)b * M * CR + slice0 + (act ? cl0 : 0);
+    const int* __restrict__ offb = offsets + (size_t)b * ((size_t)N * F + 1);
+    for (int p = p_begin + w * kBwdTWaves + wave; p < p_end; p += stride) {
+        const int n = order ? uniform(order[(size_t)b * N + p]) : p;
+        // the source's F+1 segment bounds: ONE coalesced read (lane f holds bound f), consumed with v_readlane at
+        // compile-time lanes — not 33 dependent scalar loads (measured: they dominated the sparse levels)
+        const int* __restrict__ o = offb + (size_t)n * F;
+        const int ov0 = o[lane <= F ? lane : F];
+        const int ov1 = (MAXF >= 64) ? o[(64 + lane) <= F ? (64 + lane) : F] : 0;
         float xi[VI], xv[V];
 #pragma unroll
         for (int u = 0; u < VI; u++) xi[u] = input[((size_t)b * N + n) * C + (act ? cin0 : slice0 / R) + u];
@@ -279,7 +291,8 @@ __global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
 #pragma unroll
         for (int f = 0; f < MAXF; f++) {
             if (f < F) {
-                const int e0 = o[f], e1 = o[f + 1];
+                const int e0 = __builtin_amdgcn_readlane(f < 64 ? ov0 : ov1, f & 63);
+                const int e1 = __builtin_amdgcn_readlane((f + 1) < 64 ? ov0 : ov1, (f + 1) & 63);
                 if (e0 < e1) {                               // wave-uniform: most (n, bin) segments are empty or short
                     float sg[V];
 #pragma unroll
@@ -336,6 +349,8 @@ __global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
         }
     }
 
+    }   // items
+
     // workgroup reduction of the per-wave accumulators: waves take turns on one [F][SL] LDS table
     __syncthreads();                 // everyone is done reading lfilt
     float* tab = lds;                // reuse: [F][SL]
@@ -354,7 +369,7 @@ __global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
         }
         __syncthreads();
     }
-    float* out = partial + ((size_t)b * nblocks + nb) * ((size_t)F * CR);
+    float* out = partial + ((size_t)xcd * W + w) * ((size_t)F * CR);
     for (int e = threadIdx.x; e < F * SL; e += blockDim.x) {
         const int f = e / SL;
         const int cl = e - f * SL;
@@ -527,24 +542,56 @@ static int vec_plan(int F, int CR, int r, int& V)
     return 0;
 }
 
+// persistent-sweep plan of dwconv_bwd_t_vec: `parts` position ranges per cloud so that (cloud, part) items divide
+// evenly over the 8 XCDs, and W workgroups per XCD and channel slice:
+//   * large levels: ~64 sources per workgroup (per-workgroup cost: one F x CR partial table), at most 3 per CU;
+//   * small levels (N = 128..768: the whole launch is a few hundred sources per XCD): the kernel is a chain of
+//     dependent gathers per source, so the sources are spread over enough workgroups to put two on every CU
+//     (down to 2 sources per wave) instead of leaving most CUs idle.
+static void bwd_plan(int B, int N, int nslices, int& parts, int& W)
+{
+    int g = B & 7;                         // gcd(B, 8)
+    g = g == 0 ? 8 : (g & -g);
+    parts = 8 / g;
+    if (parts > N) parts = 1;
+    const long long items_per_xcd = ((long long)B * parts + 7) / 8;
+    const long long src = items_per_xcd * ((N + parts - 1) / parts);
+    const long long w_work = (src + kBwdTPointsPerWG - 1) / kBwdTPointsPerWG;
+    long long w_fill = 64 / (nslices < 1 ? 1 : nslices);
+    if (w_fill < 1) w_fill = 1;
+    const long long w_min = (src + 2 * kBwdTWaves - 1) / (2 * kBwdTWaves);
+    long long w = w_fill < w_min ? w_fill : w_min;
+    if (w < w_work) w = w_work;
+    W = (int)(w < 1 ? 1 : (w > 96 ? 96 : w));
+}
+
+static int bwd_slices(int F, int CR, int r)
+{
+    int V = 0;
+    if (!vec_plan(F, CR, r, V)) return 0;
+    return (CR + 64 * V - 1) / (64 * V);
+}
+
 extern "C" size_t sph3d_depthwise_conv3d_grad_t_workspace(int B, int N, int F, int C, int r)
 {
     int V = 0;
     if (!vec_plan(F, C * r, r, V)) return 0;
-    const int nblocks = (N + kBwdTPointsPerWG - 1) / kBwdTPointsPerWG;
-    return sizeof(float) * (size_t)B * nblocks * F * C * r;
+    int parts, W;
+    bwd_plan(B, N, bwd_slices(F, C * r, r), parts, W);
+    return sizeof(float) * (size_t)8 * W * F * C * r;
 }
 
 template <int R, int V, int MAXF>
 static int launch_bwd_t_vec(int B, int N, int M, int F, int C, const int* offsets, const int* ent_key,
-                            const float* ent_scale, const float* input, const float* filter,
+                            const float* ent_scale, const int* order, const float* input, const float* filter,
                             const float* grad_output, float* grad_input, float* grad_filter, float* partial,
                             hipStream_t st)
 {
     const int CR = C * R;
-    const int nblocks = (N + kBwdTPointsPerWG - 1) / kBwdTPointsPerWG;
     const int SLW = 64 * V;
     const int nslices = (CR + SLW - 1) / SLW;
+    int parts, W;
+    bwd_plan(B, N, nslices, parts, W);
     const int SLmax = CR < SLW ? CR : SLW;
     const size_t lds = (size_t)F * SLmax * sizeof(float);
     auto kern = dwconv_bwd_t_vec<R, V, MAXF>;
@@ -553,16 +600,18 @@ static int launch_bwd_t_vec(int B, int N, int M, int F, int C, const int* offset
                            "conv3d: hipFuncSetAttribute");
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(kern, dim3(xcd_grid(B, nblocks * nslices)), dim3(kBwdTWaves * 64), lds, st, B, N, M, F, C,
-                       nblocks, nslices, offsets, ent_key, ent_scale, input, filter, grad_output, grad_input, partial);
+    hipLaunchKernelGGL(kern, dim3(8 * W * nslices), dim3(kBwdTWaves * 64), lds, st, B, N, M, F, C,
+                       W, parts, nslices, offsets, ent_key, ent_scale, order, input, filter, grad_output, grad_input,
+                       partial);
     const int total = F * CR;
-    hipLaunchKernelGGL(reduce_filter_partials, dim3((total + 31) / 32), dim3(256), 0, st, B * nblocks, total, partial,
+    hipLaunchKernelGGL(reduce_filter_partials, dim3((total + 31) / 32), dim3(256), 0, st, 8 * W, total, partial,
                        grad_filter);
     return check_launch("sph3d_depthwise_conv3d_grad_t");
 }
 
 extern "C" int sph3d_depthwise_conv3d_grad_t(int B, int N, int M, int F, int C, int r,
                                              const int* offsets, const int* ent_key, const float* ent_scale,
+                                             const int* source_order,
                                              const float* input, const float* filter, const float* grad_output,
                                              float* grad_input, float* grad_filter,
                                              void* workspace, size_t workspace_bytes, sph3d_stream_t stream)
@@ -581,8 +630,8 @@ extern "C" int sph3d_depthwise_conv3d_grad_t(int B, int N, int M, int F, int C, 
         }
         float* partial = (float*)workspace;
 #define SPH3D_GO(RR, VV, MF) \
-    return launch_bwd_t_vec<RR, VV, MF>(B, N, M, F, C, offsets, ent_key, ent_scale, input, filter, grad_output, \
-                                        grad_input, grad_filter, partial, st)
+    return launch_bwd_t_vec<RR, VV, MF>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, input, filter, \
+                                        grad_output, grad_input, grad_filter, partial, st)
         if (V == 4 && r == 2) SPH3D_GO(2, 4, 33);
         if (V == 4 && r == 1) SPH3D_GO(1, 4, 33);
         if (V == 2 && r == 2) SPH3D_GO(2, 2, 65);
@@ -624,12 +673,12 @@ extern "C" int sph3d_depthwise_conv3d_grad(int B, int N, int M, int F, int C, in
         set_error("DepthwiseConv3dGrad: workspace %zu B < required %zu B", workspace_bytes, need);
         return SPH3D_EWORKSPACE;
     }
-    if (B == 0) return sph3d_depthwise_conv3d_grad_t(B, N, M, F, C, r, nullptr, nullptr, nullptr, input, filter,
+    if (B == 0) return sph3d_depthwise_conv3d_grad_t(B, N, M, F, C, r, nullptr, nullptr, nullptr, nullptr, input, filter,
                                                      grad_output, grad_input, grad_filter, nullptr, 0, stream);
     TGraphWs t = tgraph_carve(workspace, B, N, M, K, F);
     rc = sph3d_graph_transpose(B, N, M, K, F, nn_index, nn_count, bin_index, nullptr, t.offsets, t.key, t.scale,
                                t.scratch, t.scratch_bytes, stream);
     if (rc) return rc;
-    return sph3d_depthwise_conv3d_grad_t(B, N, M, F, C, r, t.offsets, t.key, t.scale, input, filter, grad_output,
+    return sph3d_depthwise_conv3d_grad_t(B, N, M, F, C, r, t.offsets, t.key, t.scale, nullptr, input, filter, grad_output,
                                          grad_input, grad_filter, (char*)workspace + tg, workspace_bytes - tg, stream);
 }

@@ -68,6 +68,7 @@ def _depthwise_conv3d_grad_impl(input: torch.Tensor, filter: torch.Tensor, grad_
     ws = torch.empty((wsb,), dtype=torch.uint8, device=input.device) if wsb else None
     _lib.check(l.sph3d_depthwise_conv3d_grad_t(
         B, N, M, F, C, r, _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale),
+        _lib.ptr(_tgraph.source_order(nn_index)),
         _lib.ptr(input), _lib.ptr(filter), _lib.ptr(grad_output), _lib.ptr(grad_input), _lib.ptr(grad_filter),
         _lib.ptr(ws), wsb, _lib.stream_ptr()))
     return grad_input, grad_filter

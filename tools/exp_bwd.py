@@ -17,6 +17,18 @@ def timeit(fn,n=5):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1)/n
+def morton_order(xyz, bits=10):
+    lo = xyz.amin(dim=1, keepdim=True); hi = xyz.amax(dim=1, keepdim=True)
+    q = ((xyz - lo) / (hi - lo).clamp(min=1e-9) * (2**bits - 1)).long()
+    code = torch.zeros(xyz.shape[:2], dtype=torch.long, device=xyz.device)
+    for i in range(bits):
+        for a in range(3):
+            code |= ((q[..., a] >> i) & 1) << (3 * i + a)
+    return torch.argsort(code, dim=1).to(torch.int32).contiguous()
+MODE = os.environ.get("ORDER", "morton")
+if MODE == "morton":
+    _tgraph.set_source_order(idx, morton_order(xyz))
+print("order mode", MODE)
 for C in (128,64):
     x=torch.randn(B,N,C,device=dev); w=torch.randn(33,C,2,device=dev); go=torch.randn(B,N,C*2,device=dev)
     print("C",C,"fwd ms",timeit(lambda: tf_conv3d.depthwise_conv3d(x,w,idx,cnt,filt)))
