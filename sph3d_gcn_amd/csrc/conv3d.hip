@@ -28,13 +28,138 @@ namespace sph3d {
 
 constexpr int kSlice = 256;       // output channels per wave pass (64 lanes x 4)
 constexpr int kFwdPointsPerWG = 32;
-constexpr int kBatch = 8;        // neighbours whose gathers are issued together
+#ifndef SPH3D_FWD_SB
+#define SPH3D_FWD_SB 4
+#endif
+constexpr int kFwdSB = SPH3D_FWD_SB;   // dwconv_fwd_multi: wave loads (each EPL neighbour rows) issued together
+constexpr int kBatch = 8;               // dwconv_fwd_row: neighbours whose gathers are issued together
 
 // ------------------------------------------------------------------------------------------
-// forward, vectorised: R = depth multiplier (1 or 2), CR % 4 == 0
+// forward, vectorised: R = depth multiplier (1 or 2), C % 4 == 0.
+// A lane owns FOUR INPUT channels (one 16-B gather per edge) and their 4R output channels; an edge therefore needs
+// LPE = C/4 lanes (16 / 32 / 64 for C = 64 / 128 / >= 256) and one wave load instruction fetches EPL = 64/LPE
+// different neighbour rows, lane group g taking the edges k = g (mod EPL) of the point.  Round-1 counters that
+// forced this shape (C = 128, r = 2, one edge per load, float2 per lane): the CU's vector L1 was 83 % occupied
+// (59 % processing + 24 % stalled on pending lines) — the L1 spends 16 cycles per wave load whether the lanes ask
+// for 8 or 16 bytes and whether or not half of them repeat lane 0's address; the L2 and HBM were far from busy.
+// The group partial sums are added across lane groups at the end (ds_swizzle-free: two ds_bpermute rounds at most).
+// ------------------------------------------------------------------------------------------
+template <int R, int LPE, int SB>
+__global__ __launch_bounds__(256) void dwconv_fwd_multi(
+    int B, int N, int M, int F, int C, int K, int mblocks, int nslices,
+    const int* __restrict__ nnIndex, const int* __restrict__ nnCount, const int* __restrict__ binIndex,
+    const float* __restrict__ input, const float* __restrict__ filter, float* __restrict__ output)
+{
+    extern __shared__ __attribute__((aligned(16))) float lfilt[];   // [F][SLo]
+    constexpr int EPL = 64 / LPE;               // edges per wave load
+    constexpr int NO = 4 * R;                   // output channels per lane
+    constexpr int SLI = 4 * LPE;                // input channels per slice
+    const int CR = C * R;
+    int b, part;
+    xcd_decode((int)blockIdx.x, B, mblocks * nslices, b, part);
+    if (b < 0) return;
+    const int slice = part / mblocks;
+    const int mb = part - slice * mblocks;
+    const int ci0 = slice * SLI;                                     // first input channel of the slice
+    const int SLi = (C - ci0) < SLI ? (C - ci0) : SLI;               // multiple of 4
+    const int SLo = SLi * R;
+
+    // stage the filter slice, de-interleaved so that the lanes' 16-B reads are contiguous (conflict-free ds_read_b128):
+    // quad q of lane li (its output channels 4q..4q+3, i.e. slice columns li*4R + 4q + j) lives at [f][q][li*4 + j]
+    for (int e = threadIdx.x * 4; e < F * SLo; e += blockDim.x * 4) {
+        const int f = e / SLo;
+        const int cl = e - f * SLo;                 // multiple of 4
+        const int l4 = cl / (4 * R), q = (cl >> 2) % R;
+        *reinterpret_cast<float4*>(&lfilt[f * SLo + q * SLi + l4 * 4]) =
+            *reinterpret_cast<const float4*>(&filter[(size_t)f * CR + ci0 * R + cl]);
+    }
+    __syncthreads();
+
+    const int wave = uniform((int)threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int g = lane / LPE;                   // edge group of this lane
+    const int li = lane - g * LPE;
+    const bool act = li * 4 < SLi;
+    const int cic = act ? li * 4 : 0;           // clamped copy for branch-free loads
+    const int m_begin = mb * kFwdPointsPerWG;
+    const int m_end = (m_begin + kFwdPointsPerWG) < M ? (m_begin + kFwdPointsPerWG) : M;
+    const float* inb = input + (size_t)b * N * C + ci0 + cic;
+    const float* lw = lfilt + cic;
+
+    for (int m = m_begin + wave; m < m_end; m += 4) {
+        const size_t row = (size_t)b * M + m;
+        const int cnt = uniform(nnCount[row]);
+        float acc[NO];
+#pragma unroll
+        for (int v = 0; v < NO; v++) acc[v] = 0.f;
+        for (int kt = 0; kt < cnt; kt += 64) {
+            // the row's neighbour ids and bin ids: ONE coalesced 256-B read each (lane k holds slot kt + k) ...
+            const int myk = kt + lane;
+            const int idxv = myk < cnt ? nnIndex[row * K + myk] : 0;
+            const int binv = myk < cnt ? binIndex[row * K + myk] : 0;
+            const int kn = (cnt - kt) < 64 ? (cnt - kt) : 64;
+            // ... then consumed SB wave loads (SB*EPL edges) at a time: all their gathers are in flight before the
+            // first FMA (the kernel is latency-bound otherwise)
+            for (int k0 = 0; k0 < kn; k0 += SB * EPL) {
+                float4 x[SB];
+                int fo[SB];
+#pragma unroll
+                for (int u = 0; u < SB; u++) {
+                    // lane group g takes edge k0 + u*EPL + g.  Measured: ds_bpermute (0.145 ms at C = 64) beats EPL v_readlane
+                    // broadcasts + per-lane selects (0.203 ms) — the selects and the per-lane address arithmetic cost more
+                    // VALU time than the LDS round trip
+                    const int kq = k0 + u * EPL + g;
+                    const bool valid = kq < kn;
+                    const int kk = valid ? kq : (kn - 1);
+                    const int n = __shfl(idxv, kk);
+                    const int f = __shfl(binv, kk);
+                    // no per-lane branch: padding slots re-read a valid row and are zeroed, so the SB loads stay in
+                    // one basic block and are all in flight together
+                    const float4 t = *reinterpret_cast<const float4*>(&inb[(size_t)n * C]);
+                    x[u] = valid ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                    fo[u] = f * SLo;
+                }
+#pragma unroll
+                for (int u = 0; u < SB; u++) {
+                    const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+#pragma unroll
+                    for (int q = 0; q < R; q++) {
+                        const float4 w = *reinterpret_cast<const float4*>(&lw[fo[u] + q * SLi]);
+                        // outputs 4q..4q+3 of this lane belong to input channels (4q + j) / R
+                        acc[4 * q + 0] = fmaf(xs[(4 * q + 0) / R], w.x, acc[4 * q + 0]);
+                        acc[4 * q + 1] = fmaf(xs[(4 * q + 1) / R], w.y, acc[4 * q + 1]);
+                        acc[4 * q + 2] = fmaf(xs[(4 * q + 2) / R], w.z, acc[4 * q + 2]);
+                        acc[4 * q + 3] = fmaf(xs[(4 * q + 3) / R], w.w, acc[4 * q + 3]);
+                    }
+                }
+            }
+        }
+        // add the partial sums of the EPL lane groups (lanes li, li + LPE, ...)
+#pragma unroll
+        for (int o = LPE; o < 64; o <<= 1)
+#pragma unroll
+            for (int v = 0; v < NO; v++) acc[v] += __shfl_xor(acc[v], o);
+        if (act && g == 0) {
+            const float fc = (float)cnt;   // cnt == 0 only for rows the caller marked empty: output 0
+            float* op = &output[row * CR + (size_t)(ci0 + li * 4) * R];
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                float4 o;
+                o.x = cnt > 0 ? acc[4 * q + 0] / fc : 0.f;
+                o.y = cnt > 0 ? acc[4 * q + 1] / fc : 0.f;
+                o.z = cnt > 0 ? acc[4 * q + 2] / fc : 0.f;
+                o.w = cnt > 0 ? acc[4 * q + 3] / fc : 0.f;
+                *reinterpret_cast<float4*>(&op[4 * q]) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward, one edge per wave load (C >= 128): R = depth multiplier (1 or 2), CR % 4 == 0
 // ------------------------------------------------------------------------------------------
 template <int R>
-__global__ __launch_bounds__(256) void dwconv_fwd_vec(
+__global__ __launch_bounds__(256) void dwconv_fwd_row(
     int B, int N, int M, int F, int C, int K, int mblocks, int nslices,
     const int* __restrict__ nnIndex, const int* __restrict__ nnCount, const int* __restrict__ binIndex,
     const float* __restrict__ input, const float* __restrict__ filter, float* __restrict__ output,
@@ -458,7 +583,8 @@ static int conv_dims_ok(int B, int N, int M, int F, int C, int r, int K, const c
 {
     SPH3D_REQUIRE(B >= 0 && N > 0 && M >= 0 && F > 0 && C > 0 && r > 0 && K > 0,
                   "%s: bad dims B=%d N=%d M=%d F=%d C=%d r=%d K=%d", who, B, N, M, F, C, r, K);
-    SPH3D_REQUIRE((size_t)F * (C * r < kSlice ? C * r : kSlice) * sizeof(float) <= 160 * 1024,
+    const size_t slice = (size_t)(C * r < kSlice ? C * r : kSlice);
+    SPH3D_REQUIRE((size_t)F * slice * sizeof(float) <= 160 * 1024,
                   "%s: filter table slice F=%d does not fit LDS", who, F);
     return SPH3D_OK;
 }
@@ -477,27 +603,48 @@ extern "C" int sph3d_depthwise_conv3d(int B, int N, int M, int F, int C, int r, 
     if (B == 0 || M == 0) return SPH3D_OK;
     const int CR = C * r;
     const int mblocks = (M + kFwdPointsPerWG - 1) / kFwdPointsPerWG;
-    const int nslices = (CR + kSlice - 1) / kSlice;
-    const int SLmax = CR < kSlice ? CR : kSlice;
-    const size_t lds = (size_t)F * SLmax * sizeof(float);
-    const dim3 grid(xcd_grid(B, mblocks * nslices));
     hipStream_t st = as_stream(stream);
-    const bool vec = (CR % 4 == 0) && (r == 1 || r == 2);
+    const bool vec = (C % 4 == 0) && (r == 1 || r == 2);
 #define SPH3D_BIG_LDS(kern)                                                                                       \
     if (lds > 64 * 1024) {                                                                                        \
         rc = check_hip(hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), \
                        "conv3d: hipFuncSetAttribute");                                                            \
         if (rc) return rc;                                                                                        \
     }
-    if (vec && r == 2) {
-        SPH3D_BIG_LDS(dwconv_fwd_vec<2>)
-        hipLaunchKernelGGL(dwconv_fwd_vec<2>, grid, dim3(256), lds, st, B, N, M, F, C, K, mblocks, nslices,
-                           nn_index, nn_count, bin_index, input, filter, output, nullptr);
+    if (vec && C <= 64) {
+        // narrow layers: 16 lanes per edge, four neighbour rows per wave load (measured at C = 64, r = 2: 0.254 -> 0.145 ms;
+        // at C >= 128 the one-edge-per-load kernel below is faster: 0.297 vs 0.353 ms with two edges per load)
+        const int nslices = 1;
+        const size_t lds = (size_t)F * C * r * sizeof(float);
+        const dim3 grid(xcd_grid(B, mblocks * nslices));
+        if (r == 2) {
+            SPH3D_BIG_LDS((dwconv_fwd_multi<2, 16, kFwdSB>))
+            hipLaunchKernelGGL((dwconv_fwd_multi<2, 16, kFwdSB>), grid, dim3(256), lds, st, B, N, M, F, C, K, mblocks,
+                               nslices, nn_index, nn_count, bin_index, input, filter, output);
+        } else {
+            SPH3D_BIG_LDS((dwconv_fwd_multi<1, 16, kFwdSB>))
+            hipLaunchKernelGGL((dwconv_fwd_multi<1, 16, kFwdSB>), grid, dim3(256), lds, st, B, N, M, F, C, K, mblocks,
+                               nslices, nn_index, nn_count, bin_index, input, filter, output);
+        }
     } else if (vec) {
-        SPH3D_BIG_LDS(dwconv_fwd_vec<1>)
-        hipLaunchKernelGGL(dwconv_fwd_vec<1>, grid, dim3(256), lds, st, B, N, M, F, C, K, mblocks, nslices,
-                           nn_index, nn_count, bin_index, input, filter, output, nullptr);
+        const int nslices = (CR + kSlice - 1) / kSlice;
+        const int SLmax = CR < kSlice ? CR : kSlice;
+        const size_t lds = (size_t)F * SLmax * sizeof(float);
+        const dim3 grid(xcd_grid(B, mblocks * nslices));
+        if (r == 2) {
+            SPH3D_BIG_LDS(dwconv_fwd_row<2>)
+            hipLaunchKernelGGL(dwconv_fwd_row<2>, grid, dim3(256), lds, st, B, N, M, F, C, K, mblocks, nslices,
+                               nn_index, nn_count, bin_index, input, filter, output, nullptr);
+        } else {
+            SPH3D_BIG_LDS(dwconv_fwd_row<1>)
+            hipLaunchKernelGGL(dwconv_fwd_row<1>, grid, dim3(256), lds, st, B, N, M, F, C, K, mblocks, nslices,
+                               nn_index, nn_count, bin_index, input, filter, output, nullptr);
+        }
     } else {
+        const int nslices = (CR + kSlice - 1) / kSlice;
+        const int SLmax = CR < kSlice ? CR : kSlice;
+        const size_t lds = (size_t)F * SLmax * sizeof(float);
+        const dim3 grid(xcd_grid(B, mblocks * nslices));
         SPH3D_BIG_LDS(dwconv_fwd_generic)
         hipLaunchKernelGGL(dwconv_fwd_generic, grid, dim3(256), lds, st, B, N, M, F, C, r, K, mblocks, nslices,
                            nn_index, nn_count, bin_index, input, filter, output);
