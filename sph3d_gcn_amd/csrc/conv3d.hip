@@ -345,7 +345,13 @@ __global__ __launch_bounds__(256) void dwconv_fwd_generic(
 constexpr int kBwdTWaves = 4;
 constexpr int kBwdTPointsPerWG = 64;     // measured: 256 -> 1.90 ms, 128 -> 1.15, 64 -> 0.90, 32 -> 0.91, 16 -> 1.22 (tail / balance vs per-block setup)
 
-template <int R, int V, int MAXF>
+#ifndef SPH3D_BWD_NL
+#define SPH3D_BWD_NL 2      // measured at C = 64, r = 2, level 0: 2 loads (4 edges) per batch 0.532 ms, 4 loads 0.631, one row per load 0.589
+#endif
+// HALF (CR == 128, V == 4): a grad_out row is 32 lanes wide, so the two halves of the wave take ALTERNATE edges of
+// a segment (one wave load = two rows) and keep separate partial sums, added across the halves once per source
+// (grad_input) / once per launch (the filter accumulators).
+template <int R, int V, int MAXF, bool HALF>
 __global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
     int B, int N, int M, int F, int C, int W, int parts, int nslices,
     const int* __restrict__ offsets, const int* __restrict__ entKey, const float* __restrict__ entScale,
@@ -376,7 +382,8 @@ __global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
 
     const int wave = uniform((int)threadIdx.x >> 6);
     const int lane = lane_id();
-    const int cl0 = lane * V;
+    const int half = HALF ? (lane >> 5) : 0;
+    const int cl0 = (HALF ? (lane & 31) : lane) * V;
     const bool act = cl0 < SL;
     const int cin0 = (slice0 + cl0) / R;
     const int stride = W * kBwdTWaves;          // waves of this XCD that sweep a cloud side by side
@@ -422,6 +429,33 @@ __global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
                     float sg[V];
 #pragma unroll
                     for (int v = 0; v < V; v++) sg[v] = 0.f;
+                    if (HALF) {
+                        constexpr int NL = SPH3D_BWD_NL;          // wave loads per batch = 2 * NL edges
+                        for (int e = e0; e < e1; e += 2 * NL) {
+                            int mm[NL];
+                            float sc[NL];
+#pragma unroll
+                            for (int u = 0; u < NL; u++) {
+                                const int ia = e + 2 * u, ib = ia + 1;
+                                const int ca = ia < e1 ? ia : (e1 - 1), cb = ib < e1 ? ib : (e1 - 1);
+                                const int ma = entKey[ca], mb = entKey[cb];
+                                const float sa = ia < e1 ? entScale[ca] : 0.f;      // padding edges contribute exactly 0
+                                const float sb = ib < e1 ? entScale[cb] : 0.f;
+                                mm[u] = half ? mb : ma;
+                                sc[u] = half ? sb : sa;
+                            }
+                            float g[NL][V];
+#pragma unroll
+                            for (int u = 0; u < NL; u++) {
+                                const float4 t = *reinterpret_cast<const float4*>(&gob[(unsigned)mm[u] * (unsigned)CR]);
+                                g[u][0] = t.x; g[u][1 % V] = t.y; g[u][2 % V] = t.z; g[u][3 % V] = t.w;
+                            }
+#pragma unroll
+                            for (int u = 0; u < NL; u++)
+#pragma unroll
+                                for (int v = 0; v < V; v++) sg[v] = fmaf(g[u][v], sc[u], sg[v]);
+                        }
+                    } else
                     for (int e = e0; e < e1; e += 4) {
                         // four edges at a time: their row gathers are independent and issued together
                         int mm[4];
@@ -460,7 +494,11 @@ __global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
                 }
             }
         }
-        if (act) {
+        if (HALF) {
+#pragma unroll
+            for (int v = 0; v < V; v++) gi[v] += __shfl_xor(gi[v], 32);
+        }
+        if (act && half == 0) {
             float* gp = &gradInput[((size_t)b * N + n) * C + cin0];
             if (V >= R) {
 #pragma unroll
@@ -476,11 +514,17 @@ __global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
 
     }   // items
 
+    if (HALF) {
+#pragma unroll
+        for (int i = 0; i < MAXF; i++)
+#pragma unroll
+            for (int v = 0; v < V; v++) acc[i][v] += __shfl_xor(acc[i][v], 32);
+    }
     // workgroup reduction of the per-wave accumulators: waves take turns on one [F][SL] LDS table
     __syncthreads();                 // everyone is done reading lfilt
     float* tab = lds;                // reuse: [F][SL]
     for (int w = 0; w < kBwdTWaves; w++) {
-        if (wave == w && act) {
+        if (wave == w && act && half == 0) {
 #pragma unroll
             for (int i = 0; i < MAXF; i++) {
                 if (i < F) {
@@ -728,7 +772,7 @@ extern "C" size_t sph3d_depthwise_conv3d_grad_t_workspace(int B, int N, int F, i
     return sizeof(float) * (size_t)8 * W * F * C * r;
 }
 
-template <int R, int V, int MAXF>
+template <int R, int V, int MAXF, bool HALF>
 static int launch_bwd_t_vec(int B, int N, int M, int F, int C, const int* offsets, const int* ent_key,
                             const float* ent_scale, const int* order, const float* input, const float* filter,
                             const float* grad_output, float* grad_input, float* grad_filter, float* partial,
@@ -741,7 +785,7 @@ static int launch_bwd_t_vec(int B, int N, int M, int F, int C, const int* offset
     bwd_plan(B, N, nslices, parts, W);
     const int SLmax = CR < SLW ? CR : SLW;
     const size_t lds = (size_t)F * SLmax * sizeof(float);
-    auto kern = dwconv_bwd_t_vec<R, V, MAXF>;
+    auto kern = dwconv_bwd_t_vec<R, V, MAXF, HALF>;
     if (lds > 64 * 1024) {
         int rc = check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                            "conv3d: hipFuncSetAttribute");
@@ -777,8 +821,14 @@ extern "C" int sph3d_depthwise_conv3d_grad_t(int B, int N, int M, int F, int C, 
         }
         float* partial = (float*)workspace;
 #define SPH3D_GO(RR, VV, MF) \
-    return launch_bwd_t_vec<RR, VV, MF>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, input, filter, \
+    return launch_bwd_t_vec<RR, VV, MF, false>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, input, filter, \
                                         grad_output, grad_input, grad_filter, partial, st)
+        if (V == 4 && CR == 128 && r == 2)
+            return launch_bwd_t_vec<2, 4, 33, true>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, input, filter,
+                                                    grad_output, grad_input, grad_filter, partial, st);
+        if (V == 4 && CR == 128 && r == 1)
+            return launch_bwd_t_vec<1, 4, 33, true>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, input, filter,
+                                                    grad_output, grad_input, grad_filter, partial, st);
         if (V == 4 && r == 2) SPH3D_GO(2, 4, 33);
         if (V == 4 && r == 1) SPH3D_GO(1, 4, 33);
         if (V == 2 && r == 2) SPH3D_GO(2, 2, 65);

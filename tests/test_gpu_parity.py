@@ -134,7 +134,8 @@ def _graph(kind, B, N, M, K, radius, seed):
 # (B, N, M, C, r, K)
 CONV_CASES = [(2, 200, 100, 8, 2, 16), (1, 64, 64, 3, 1, 8), (2, 300, 300, 35, 2, 32), (2, 256, 256, 67, 1, 64),
               (2, 500, 500, 64, 2, 64), (1, 300, 150, 128, 2, 64), (1, 128, 128, 1024, 2, 64), (2, 200, 200, 131, 1, 16),
-              (1, 100, 100, 64, 1, 70), (2, 128, 128, 6, 4, 16)]
+              (1, 100, 100, 64, 1, 70), (2, 128, 128, 6, 4, 16), (2, 300, 300, 128, 1, 48), (1, 257, 257, 32, 2, 40),
+              (3, 150, 150, 60, 1, 24)]
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "B%d-N%d-M%d-C%d-r%d-K%d" % c)
