@@ -1,0 +1,29 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from sph3d_gcn_amd import _lib, tf_nnquery, tf_buildkernel, _tgraph
+from sph3d_gcn_amd.harness import synth
+dev=torch.device('cuda:0'); _lib.lib()
+B,N,K=16,8192,64
+xyz=torch.from_numpy(synth.s3dis_batch(1000,B,N)[0]).to(dev)[:, :, :3].contiguous()
+idx,cnt,dst=tf_nnquery.build_sphere_neighbor(xyz,xyz,0.1,None,K)
+filt=tf_buildkernel.spherical_kernel(xyz,xyz,idx,cnt,dst,0.1,[8,2,2])
+def run():
+    _tgraph.clear()
+    return _tgraph.transpose(idx,cnt,N,bin_index=filt,num_bins=33)
+off,key,sc=run(); torch.cuda.synchronize()
+import numpy as np
+o=off.view(B,N*33+1).cpu().numpy()
+deg=np.diff(o,axis=1)
+# reference count on host
+ii=idx.cpu().numpy(); cc=cnt.cpu().numpy(); ff=filt.cpu().numpy()
+ref=np.zeros((B,N*33),np.int64)
+for b in range(B):
+    m=np.arange(K)[None,:]<cc[b][:,None]
+    k=(ii[b]*33+ff[b])[m]
+    ref[b]=np.bincount(k,minlength=N*33)
+print("count exact:", bool((deg==ref).all()), "nnz", int(ref.sum()))
+e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): run()
+e1.record(); torch.cuda.synchronize(); print("transpose ms", e0.elapsed_time(e1)/10)
