@@ -129,3 +129,73 @@ def test_gloo_world2_flat_grad_allreduce():
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "GLOO_OK" in p.stdout
+
+
+def test_modelnet_small_net_on_oracle_ops():
+    """SPH3D_modelnet call pattern (BASELINE config #1): 1024 points, raw-xyz concatenation (odd channel
+    counts 35 / 67), per-level global max-pools, global conv with K = remaining points and 17 bins, fc + dropout."""
+    from sph3d_gcn_amd.harness import modelnet_net
+    cfg = modelnet_net.small_config(1024)
+    pts = torch.from_numpy(synth.modelnet_batch(0, 2, 1024))
+    label = torch.tensor([3, 17])
+    with torch_ops.patched_util():
+        model = modelnet_net.SPH3DModelNet(cfg, device=torch.device("cpu"))
+        gen = torch.Generator().manual_seed(5)
+        pred, _ = model(pts, is_training=True, dropout_generator=gen)
+        loss = model.loss(pred, label)
+        loss.backward()
+    assert pred.shape == (2, 40)
+    assert torch.isfinite(pred).all() and torch.isfinite(loss)
+    params = dict(model.named_parameters())
+    # depthwise filters: conv1_1 sees mlp(32) + raw xyz(3) = 35 channels, conv2_1 64 + 3 = 67; the global conv has 17 bins
+    assert tuple(params["store.params.conv1_1/depthwise_weights"].shape) == (33, 35, 2)
+    assert tuple(params["store.params.conv2_1/depthwise_weights"].shape) == (33, 67, 1)
+    assert tuple(params["store.params.global_conv/depthwise_weights"].shape) == (17, 128, 2)
+    # fc1 input = the per-level global max-pools (64 + 128) + the global conv output
+    assert tuple(params["store.params.fc1/weights"].shape) == (64 + 128 + cfg.global_channels, 512)
+    for n, p in params.items():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+    # the loss carries the weight-decay collection and the BN regularisers (train_modelnet.py:162-164)
+    with torch_ops.patched_util():
+        pred2, _ = model(pts, is_training=False)
+    plain = modelnet_net.get_loss(pred2, label)
+    assert model.loss(pred2, label) > plain
+    assert len(model.store._decay) > 0 and len(model.store._reg) > 0
+
+
+def test_full_modelnet_plan_parameter_count():
+    """the ModelNet net (10000 points) has 788 396 parameters; the plan runs here on 1000-point clouds with
+    the same channel plan (the parameter count does not depend on the point count)."""
+    from sph3d_gcn_amd.harness import modelnet_net
+    cfg = modelnet_net.modelnet_config(10000)
+    assert cfg.num_sample == [2500, 625, 156]
+    cfg.num_input = 1000
+    cfg.num_sample = [250, 62, 15]
+    cfg.nn_uplimit = [16, 16, 16]
+    pts = torch.from_numpy(synth.modelnet_batch(7, 1, 1000))
+    with torch_ops.patched_util():
+        model = modelnet_net.SPH3DModelNet(cfg, device=torch.device("cpu"))
+        pred, _ = model(pts, is_training=False)
+    assert pred.shape == (1, 40)
+    assert sum(p.numel() for p in model.parameters()) == 788396
+
+
+def test_shapenet_small_net_on_oracle_ops():
+    """SPH3D_shapenet call pattern: raw xyz features, encoder keeps the mlp1 output, mlp2 + skip head."""
+    from sph3d_gcn_amd.harness import shapenet_net
+    cfg = shapenet_net.small_config(512)
+    pts = torch.from_numpy(synth.modelnet_batch(20, 2, 512))
+    label = torch.randint(0, 3, (2, 512), generator=torch.Generator().manual_seed(1))
+    with torch_ops.patched_util():
+        model = shapenet_net.SPH3DShapeNet(3, cfg, device=torch.device("cpu"))
+        pred, end = model(pts, is_training=True)
+        loss = model.loss(pred, label)
+        loss.backward()
+    assert pred.shape == (2, 512, 3)
+    assert end['feats'].shape == (2, 512, 2 * cfg.mlp)
+    assert torch.isfinite(pred).all() and torch.isfinite(loss)
+    params = dict(model.named_parameters())
+    assert tuple(params["store.params.mlp1/weights"].shape) == (3, cfg.mlp)
+    assert tuple(params["store.params.logits/weights"].shape) == (2 * cfg.mlp, 3)
+    for n, p in params.items():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n

@@ -526,3 +526,54 @@ def test_scannet_stress_65536_points(dev):
     m = 300
     fps = _n(tf_sample.farthest_point_sample(m, xt))
     np.testing.assert_array_equal(fps, oracle.farthest_point_sample(m, xyz))
+
+
+def _run_net(kind, device):
+    """One forward + backward of a reduced SPH3D plan with seed-7 weights; on CPU through the oracle ops, on the GPU
+    through the HIP ops.  Returns (logits, loss, {name: grad})."""
+    from oracle import torch_ops
+    from sph3d_gcn_amd.harness import modelnet_net, s3dis_net, shapenet_net
+    import contextlib
+    cpu = device.type == "cpu"
+    ctx = torch_ops.patched_util() if cpu else contextlib.nullcontext()
+    with ctx:
+        if kind == "s3dis":
+            cfg = s3dis_net.small_config(1024)
+            xyz, label, inner = synth.s3dis_batch(0, 2, 1024, extent=(1.0, 1.0, 1.5))
+            model = s3dis_net.SPH3DS3DIS(cfg, device=device)
+            pred, _ = model(torch.from_numpy(xyz).to(device), is_training=True)
+            loss = model.loss(pred, torch.from_numpy(label).to(device), torch.from_numpy(inner).to(device))
+        elif kind == "modelnet":
+            cfg = modelnet_net.small_config(1024)
+            pts = torch.from_numpy(synth.modelnet_batch(0, 2, 1024)).to(device)
+            model = modelnet_net.SPH3DModelNet(cfg, device=device)
+            pred, _ = model(pts, is_training=True, dropout_generator=torch.Generator().manual_seed(5))
+            loss = model.loss(pred, torch.tensor([3, 17], device=device))
+        else:
+            cfg = shapenet_net.small_config(512)
+            pts = torch.from_numpy(synth.modelnet_batch(20, 2, 512)).to(device)
+            label = torch.randint(0, 3, (2, 512), generator=torch.Generator().manual_seed(1)).to(device)
+            model = shapenet_net.SPH3DShapeNet(3, cfg, device=device)
+            pred, _ = model(pts, is_training=True)
+            loss = model.loss(pred, label)
+        loss.backward()
+    grads = {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters()}
+    return pred.detach().cpu().numpy(), float(loss.detach()), grads
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["s3dis", "modelnet", "shapenet"])
+def test_model_graphs_end_to_end_vs_oracle(dev, kind):
+    """the three model call patterns (models/SPH3D_s3dis.py, SPH3D_modelnet.py, SPH3D_shapenet.py), reduced
+    plans, same seed-7 weights: HIP ops on the GPU against the oracle ops on the CPU — logits, loss and every parameter
+    gradient.  Tolerance 2e-3 of the tensor's scale: ~20 fp32 layers with batch normalisation between the two ends."""
+    pred_o, loss_o, grads_o = _run_net(kind, torch.device("cpu"))
+    pred, loss, grads = _run_net(kind, dev)
+    assert pred.shape == pred_o.shape
+    s = max(1.0, float(np.abs(pred_o).max()))
+    np.testing.assert_allclose(pred / s, pred_o / s, rtol=0, atol=2e-3)
+    assert abs(loss - loss_o) <= 2e-3 * max(1.0, abs(loss_o))
+    assert grads.keys() == grads_o.keys()
+    for n in grads_o:
+        s = max(1e-3, float(np.abs(grads_o[n]).max()))
+        np.testing.assert_allclose(grads[n] / s, grads_o[n] / s, rtol=0, atol=5e-3, err_msg=n)
