@@ -115,7 +115,10 @@ __global__ __launch_bounds__(256) void dwconv_fwd_multi(
                     const int f = __shfl(binv, kk);
                     // no per-lane branch: padding slots re-read a valid row and are zeroed, so the SB loads stay in
                     // one basic block and are all in flight together
-                    const float4 t = *reinterpret_cast<const float4*>(&inb[(size_t)n * C]);
+                    float4 t = *reinterpret_cast<const float4*>(&inb[(size_t)n * C]);
+                    // the (clamped, always legal) read must stay unconditional: otherwise the compiler sinks it under `valid`
+                    // and every step becomes an exec-masked block with its own wait (measured 0.135 -> 0.129 ms)
+                    asm volatile("" : "+v"(t.x), "+v"(t.y), "+v"(t.z), "+v"(t.w));
                     x[u] = valid ? t : make_float4(0.f, 0.f, 0.f, 0.f);
                     fo[u] = f * SLo;
                 }
