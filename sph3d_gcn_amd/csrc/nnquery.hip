@@ -64,7 +64,11 @@ __device__ __forceinline__ void stage_cloud(const float* __restrict__ dbi, int c
     }
 }
 
-template <int CPW, bool MULTI>
+// DEFER: the hits of a query are collected as bare indices in a per-chain LDS list during the scan, and the outputs of
+// the finished query (indices, sqrt(sqrt(d2)), zero fill) are produced by ONE coalesced pass over its <= K slots.  The
+// first version wrote nn_index / nn_dist from inside the strip loop: every strip with at least one hit ran two
+// correctly rounded sqrtf and two scattered stores on the whole wave (~40 such strips per query at S3DIS level 0).
+template <int CPW, bool MULTI, bool DEFER>
 __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
     int B, int N, int M, int K, float radius0, int chunkN, int groups,
     const float* __restrict__ database, const float* __restrict__ query,
@@ -74,6 +78,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
     const float* lx = lds;
     const float* ly = lds + chunkN;
     const float* lz = lds + 2 * chunkN;
+    int* lhits = reinterpret_cast<int*>(lds + 3 * chunkN);      // [wave][CPW][K] when DEFER
 
     const int nt = M < kRefBlock ? M : kRefBlock;
     const int bb = (int)blockIdx.x / groups;     // reference block id  (= cloud index mod 32)
@@ -154,9 +159,13 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
                             if (mask != 0ull) {
                                 const int pos = s[c] + prefix_popc(mask);
                                 if (hit && pos < K) {
-                                    const size_t o = ((size_t)i * M + j[c]) * K + pos;
-                                    nnIndex[o] = c0 + k;
-                                    nnDist[o] = sqrtf(sqrtf(d2));   // :47 then :54 — sqrt of the distance
+                                    if (DEFER) {
+                                        lhits[(wave * CPW + c) * K + pos] = c0 + k;
+                                    } else {
+                                        const size_t o = ((size_t)i * M + j[c]) * K + pos;
+                                        nnIndex[o] = c0 + k;
+                                        nnDist[o] = sqrtf(sqrtf(d2));   // :47 then :54 — sqrt of the distance
+                                    }
                                 }
                                 s[c] += __popcll(mask);
                             }
@@ -175,9 +184,28 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
                         const int cnt = s[c] < K ? s[c] : K;
                         const size_t row = (size_t)i * M + j[c];
                         if (lane == 0) nnCount[row] = cnt;
-                        for (int slot = cnt + lane; slot < K; slot += 64) {   // unused slots read 0
-                            nnIndex[row * K + slot] = 0;
-                            nnDist[row * K + slot] = 0.0f;
+                        if (DEFER) {
+                            // the query's K output slots in one coalesced pass: distance recomputed from the same operands
+                            const int* h = lhits + (wave * CPW + c) * K;
+                            for (int slot = lane; slot < K; slot += 64) {
+                                int id = 0;
+                                float dist = 0.0f;
+                                if (slot < cnt) {
+                                    id = h[slot];
+                                    const float dx = dbi[(size_t)id * 3] - qx[c];
+                                    const float dy = dbi[(size_t)id * 3 + 1] - qy[c];
+                                    const float dz = dbi[(size_t)id * 3 + 2] - qz[c];
+                                    const float d2 = (dx * dx + dy * dy) + dz * dz;   // tf_nnquery_gpu.cu:45-46
+                                    dist = sqrtf(sqrtf(d2));                          // :47 then :54 — sqrt of the distance
+                                }
+                                nnIndex[row * K + slot] = id;                          // unused slots read 0
+                                nnDist[row * K + slot] = dist;
+                            }
+                        } else {
+                            for (int slot = cnt + lane; slot < K; slot += 64) {   // unused slots read 0
+                                nnIndex[row * K + slot] = 0;
+                                nnDist[row * K + slot] = 0.0f;
+                            }
                         }
                         j[c] += kRefBlock;
                         has[c] = j[c] < M;
@@ -240,7 +268,14 @@ __global__ __launch_bounds__(256) void nnquery_cube_kernel(
     }
 }
 
-template <int CPW, bool MULTI>
+// bytes of LDS for the deferred hit lists (0 = write hits from inside the scan: K too large for LDS lists)
+static size_t hits_bytes(int CPW, int K)
+{
+    const size_t b = sizeof(int) * (size_t)kWavesPerWG * CPW * K;
+    return b <= 40 * 1024 ? b : 0;
+}
+
+template <int CPW, bool MULTI, bool DEFER>
 static int launch_sphere(int B, int N, int M, int K, float radius, int chunkN,
                          const float* database, const float* query,
                          int* nn_index, int* nn_count, float* nn_dist, hipStream_t stream)
@@ -248,8 +283,8 @@ static int launch_sphere(int B, int N, int M, int K, float radius, int chunkN,
     const int nb = B < kRefGrid ? B : kRefGrid;
     const int nt = M < kRefBlock ? M : kRefBlock;
     const int groups = (nt + kWavesPerWG * CPW - 1) / (kWavesPerWG * CPW);
-    const size_t lds = (size_t)3 * chunkN * sizeof(float);
-    auto kern = nnquery_sphere_kernel<CPW, MULTI>;
+    const size_t lds = (size_t)3 * chunkN * sizeof(float) + (DEFER ? hits_bytes(CPW, K) : 0);
+    auto kern = nnquery_sphere_kernel<CPW, MULTI, DEFER>;
     if (lds > 64 * 1024) {
         int rc = check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                            "nnquery: hipFuncSetAttribute");
@@ -274,15 +309,28 @@ extern "C" int sph3d_build_sphere_neighbor(int B, int N, int M, int nn_sample, f
     SPH3D_REQUIRE(B >= 0 && N > 0 && M >= 0, "BuildSphereNeighbor: bad dims B=%d N=%d M=%d", B, N, M);
     if (B == 0 || M == 0) return SPH3D_OK;
     hipStream_t st = as_stream(stream);
-    const int chunkN = N < kMaxChunk ? N : kMaxChunk;
-    const bool multi = N > chunkN;
     const long long chains = (long long)(B < kRefGrid ? B : kRefGrid) * (M < kRefBlock ? M : kRefBlock);
-    if (multi) return launch_sphere<1, true>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st);
-    if (chains >= 256LL * kWavesPerWG * 4)
-        return launch_sphere<4, false>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st);
-    if (chains >= 256LL * kWavesPerWG * 2)
-        return launch_sphere<2, false>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st);
-    return launch_sphere<1, false>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st);
+    const int cpw = chains >= 256LL * kWavesPerWG * 4 ? 4 : (chains >= 256LL * kWavesPerWG * 2 ? 2 : 1);
+    // LDS: the cloud chunk (12 B per point) next to the deferred hit lists
+    size_t hb = hits_bytes(cpw, nn_sample);
+    int maxChunk = (int)((160 * 1024 - hb) / 12) & ~63;
+    if (maxChunk > kMaxChunk) maxChunk = kMaxChunk;
+    int chunkN = N < maxChunk ? N : maxChunk;
+    const bool multi = N > chunkN;
+    if (multi) {
+        hb = hits_bytes(1, nn_sample);
+        maxChunk = (int)((160 * 1024 - hb) / 12) & ~63;
+        if (maxChunk > kMaxChunk) maxChunk = kMaxChunk;
+        chunkN = maxChunk;
+    }
+#define SPH3D_NN(CP, MU)                                                                                          \
+    return hb ? launch_sphere<CP, MU, true>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st) \
+              : launch_sphere<CP, MU, false>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st)
+    if (multi) { SPH3D_NN(1, true); }
+    if (cpw == 4) { SPH3D_NN(4, false); }
+    if (cpw == 2) { SPH3D_NN(2, false); }
+    SPH3D_NN(1, false);
+#undef SPH3D_NN
 }
 
 extern "C" int sph3d_build_cube_neighbor(int B, int N, int M, int grid_size, int nn_sample, float length,
