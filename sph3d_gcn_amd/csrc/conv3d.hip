@@ -550,20 +550,20 @@ __global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
 }
 
 // grad_filter[j] = sum over the B*nblocks partial tables, fixed order -> deterministic given the partials.
-// 256 threads = 32 outputs x 8 partial-lanes (a one-thread-per-output loop over ~1000 slabs is latency-bound).
-__global__ __launch_bounds__(256) void reduce_filter_partials(int nparts, int total, const float* __restrict__ partial,
+// 1024 threads = 32 outputs x 32 partial-lanes (a one-thread-per-output loop over ~1000 slabs is latency-bound; 8 lanes: 20-30 us).
+__global__ __launch_bounds__(1024) void reduce_filter_partials(int nparts, int total, const float* __restrict__ partial,
                                                               float* __restrict__ gradFilter)
 {
-    __shared__ float red[8][32];
+    __shared__ float red[32][32];      // 32 outputs x 32 partial-lanes
     const int cx = (int)threadIdx.x & 31, py = (int)threadIdx.x >> 5;
     const int j = blockIdx.x * 32 + cx;
     float s = 0.f;
     if (j < total)
-        for (int p = py; p < nparts; p += 8) s += partial[(size_t)p * total + j];
+        for (int p = py; p < nparts; p += 32) s += partial[(size_t)p * total + j];
     red[py][cx] = s;
     __syncthreads();
     if (py == 0 && j < total) {
-        for (int k = 1; k < 8; k++) s += red[k][cx];
+        for (int k = 1; k < 32; k++) s += red[k][cx];
         gradFilter[j] = s;
     }
 }
@@ -798,7 +798,7 @@ static int launch_bwd_t_vec(int B, int N, int M, int F, int C, const int* offset
                        W, parts, nslices, offsets, ent_key, ent_scale, order, input, filter, grad_output, grad_input,
                        partial);
     const int total = F * CR;
-    hipLaunchKernelGGL(reduce_filter_partials, dim3((total + 31) / 32), dim3(256), 0, st, 8 * W, total, partial,
+    hipLaunchKernelGGL(reduce_filter_partials, dim3((total + 31) / 32), dim3(1024), 0, st, 8 * W, total, partial,
                        grad_filter);
     return check_launch("sph3d_depthwise_conv3d_grad_t");
 }

@@ -75,15 +75,17 @@ __global__ __launch_bounds__(256) void norm_reduce_kernel(int R, int C, const fl
     }
 }
 
-// Sum the per-workgroup partials of 32 channels with 256 threads (8 partial-lanes per channel, double precision, fixed
-// order); the result is valid for threads with py == 0.  (A one-thread-per-channel loop over 1024 partials took 67 us.)
+// Sum the per-workgroup partials of 32 channels with 1024 threads (32 partial-lanes per channel, double precision, fixed
+// order); the result is valid for threads with py == 0.  (A one-thread-per-channel loop over 1024 partials took 67 us,
+// 8 partial-lanes per channel 12 us per finalize launch = 0.4 ms per step over the 34 launches.)
+constexpr int kFinLanes = 32;
 __device__ __forceinline__ void sum_partials_32x8(int C, int nblk, const float* __restrict__ partial, int c, int py,
                                                   double& s, double& q)
 {
-    __shared__ double red[2][8][32];
+    __shared__ double red[2][kFinLanes][32];
     s = 0.0; q = 0.0;
     if (c < C) {
-        for (int k = py; k < nblk; k += 8) {
+        for (int k = py; k < nblk; k += kFinLanes) {
             s += (double)partial[(size_t)k * 2 * C + c];
             q += (double)partial[(size_t)k * 2 * C + C + c];
         }
@@ -93,13 +95,13 @@ __device__ __forceinline__ void sum_partials_32x8(int C, int nblk, const float* 
     red[1][py][cx] = q;
     __syncthreads();
     if (py == 0) {
-        for (int j = 1; j < 8; j++) { s += red[0][j][cx]; q += red[1][j][cx]; }
+        for (int j = 1; j < kFinLanes; j++) { s += red[0][j][cx]; q += red[1][j][cx]; }
     }
 }
 
 // forward finalize: mean / rstd from the partials (double), running statistics update (torch / TF convention:
 // running = (1-m)*running + m*batch, running_var with the unbiased batch variance)
-__global__ void norm_fwd_finalize(int R, int C, int nblk, const float* __restrict__ partial, float eps, float momentum,
+__global__ __launch_bounds__(1024) void norm_fwd_finalize(int R, int C, int nblk, const float* __restrict__ partial, float eps, float momentum,
                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
                                   float* __restrict__ run_var)
 {
@@ -131,7 +133,7 @@ __global__ void norm_eval_stats(int C, const float* __restrict__ run_mean, const
 }
 
 // backward finalize: dgamma, dbeta, and the two per-channel means the apply pass needs
-__global__ void norm_bwd_finalize(int R, int C, int nblk, int training, const float* __restrict__ partial,
+__global__ __launch_bounds__(1024) void norm_bwd_finalize(int R, int C, int nblk, int training, const float* __restrict__ partial,
                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
                                   float* __restrict__ coef /* [2][C]: dbeta/R, dgamma/R (0 in inference mode) */)
 {
@@ -217,7 +219,7 @@ extern "C" int sph3d_elu_bn_forward(int R, int C, const float* y, const float* g
     const int nblk = norm_blocks(R);
     if (training) {
         hipLaunchKernelGGL(norm_reduce_kernel<false>, dim3(nblk), dim3(256), 0, st, R, C, y, nullptr, nullptr, nullptr, partial);
-        hipLaunchKernelGGL(norm_fwd_finalize, dim3((C + 31) / 32), dim3(256), 0, st, R, C, nblk, partial, eps, momentum,
+        hipLaunchKernelGGL(norm_fwd_finalize, dim3((C + 31) / 32), dim3(32 * kFinLanes), 0, st, R, C, nblk, partial, eps, momentum,
                            save_mean, save_rstd, running_mean, running_var);
     } else {
         SPH3D_REQUIRE(running_mean != nullptr && running_var != nullptr, "elu_bn: inference needs running statistics");
@@ -248,7 +250,7 @@ extern "C" int sph3d_elu_bn_backward(int R, int C, const float* y, const float* 
     const int nblk = norm_blocks(R);
     float* coef = partial + (size_t)nblk * 2 * C;
     hipLaunchKernelGGL(norm_reduce_kernel<true>, dim3(nblk), dim3(256), 0, st, R, C, y, dout, save_mean, save_rstd, partial);
-    hipLaunchKernelGGL(norm_bwd_finalize, dim3((C + 31) / 32), dim3(256), 0, st, R, C, nblk, training, partial, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(norm_bwd_finalize, dim3((C + 31) / 32), dim3(32 * kFinLanes), 0, st, R, C, nblk, training, partial, dgamma, dbeta, coef);
     const long long total4 = (long long)R * C / 4;
     long long blocks = (total4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
