@@ -256,20 +256,21 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? 4 : 2) void gemm_f32_mf
     }
 }
 
-__global__ __launch_bounds__(1024) void gemm_reduce_splits(int nsplit, int total, const float* __restrict__ partial,
+__global__ __launch_bounds__(256) void gemm_reduce_splits(int nsplit, int total, const float* __restrict__ partial,
                                                           float* __restrict__ out)
 {
-    // 1024 threads = 32 outputs x 32 split-lanes, fixed summation order (deterministic)
-    __shared__ float red[32][32];      // 32 outputs x 32 partial-lanes
+    // 256 threads = 32 outputs x 8 split-lanes, fixed summation order (deterministic); the split count is small (<= 32):
+    // 32 lanes per output measured slower (15.8 vs 10.7 us per call)
+    __shared__ float red[8][32];
     const int cx = (int)threadIdx.x & 31, py = (int)threadIdx.x >> 5;
     const int j = blockIdx.x * 32 + cx;
     float s = 0.f;
     if (j < total)
-        for (int p = py; p < nsplit; p += 32) s += partial[(size_t)p * total + j];
+        for (int p = py; p < nsplit; p += 8) s += partial[(size_t)p * total + j];
     red[py][cx] = s;
     __syncthreads();
     if (py == 0 && j < total) {
-        for (int k = 1; k < 32; k++) s += red[k][cx];
+        for (int k = 1; k < 8; k++) s += red[k][cx];
         out[j] = s;
     }
 }
@@ -373,7 +374,7 @@ extern "C" int sph3d_pointwise_gemm_tn(int R, int Cin, int Cout, const float* X,
 #undef SPH3D_TN
     if (nsplit > 1) {
         const int total = Cin * Cout;
-        hipLaunchKernelGGL(gemm_reduce_splits, dim3((total + 31) / 32), dim3(1024), 0, st, nsplit, total, out, dW);
+        hipLaunchKernelGGL(gemm_reduce_splits, dim3((total + 31) / 32), dim3(256), 0, st, nsplit, total, out, dW);
     }
     return check_launch("sph3d_pointwise_gemm_tn");
 }

@@ -58,6 +58,15 @@ class FlatGradAllReduce:
     def zero(self):
         self.flat.zero_()
 
+    def backward(self, loss):
+        """loss.backward() for the flat layout: the parameter gradients are taken with torch.autograd.grad and written
+        into the flat buffer by ONE concatenation.  (Through the .grad views every parameter costs its own in-place `add`
+        launch — 69 of them, 0.35 ms of 5-us kernels per S3DIS step — and the buffer must be zeroed first.)"""
+        grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+        parts = [(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(grads, self.params)]
+        torch.cat(parts, out=self.flat)
+        return self.flat
+
     def all_reduce(self, average=False):
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)

@@ -50,8 +50,7 @@ def small_config(num_input=1024):
 
 def normalize_xyz(points):
     """models/SPH3D_s3dis.py:11-19"""
-    min_xyz = points.min(dim=1, keepdim=True)[0]
-    max_xyz = points.max(dim=1, keepdim=True)[0]
+    min_xyz, max_xyz = torch.aminmax(points, dim=1, keepdim=True)      # one reduction kernel instead of two
     center = (max_xyz + min_xyz) / 2
     xy = points[:, :, 0:2] - center[:, :, 0:2]
     z = points[:, :, 2:]
