@@ -24,7 +24,7 @@ namespace sph3d {
 
 __global__ __launch_bounds__(256) void tg_count(int B, int N, int M, int K, int F, const int* __restrict__ nnIndex,
                                                 const int* __restrict__ nnCount, const int* __restrict__ binIndex,
-                                                int* __restrict__ deg)
+                                                int* __restrict__ deg, int* __restrict__ slotPos)
 {
     const long long total = (long long)B * M * K;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -35,7 +35,9 @@ __global__ __launch_bounds__(256) void tg_count(int B, int N, int M, int K, int 
             const int b = (int)(row / M);
             int f = binIndex ? binIndex[e] : 0;
             f = f < 0 ? 0 : (f >= F ? F - 1 : f);       // memory safety for out-of-range bin ids
-            atomicAdd(&deg[((size_t)b * N + nnIndex[e]) * F + f], 1);
+            // the value the atomic returns is the edge's position inside its segment: kept, so that the fill pass needs
+            // no second round of atomics (measured: count 0.25 + fill 0.32 ms -> see DESIGN.md)
+            slotPos[e] = atomicAdd(&deg[((size_t)b * N + nnIndex[e]) * F + f], 1);
         }
     }
 }
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void tg_apply(int L, int chunks, int* __restri
 __global__ __launch_bounds__(256) void tg_fill(int B, int N, int M, int K, int F, const int* __restrict__ nnIndex,
                                                const int* __restrict__ nnCount, const int* __restrict__ binIndex,
                                                const float* __restrict__ weight, const int* __restrict__ offsets,
-                                               int* __restrict__ cursor, int* __restrict__ entKey,
+                                               const int* __restrict__ slotPos, int* __restrict__ entKey,
                                                float* __restrict__ entScale)
 {
     const long long total = (long long)B * M * K;
@@ -143,8 +145,7 @@ __global__ __launch_bounds__(256) void tg_fill(int B, int N, int M, int K, int F
             int f = binIndex ? binIndex[e] : 0;
             f = f < 0 ? 0 : (f >= F ? F - 1 : f);
             const size_t seg = (size_t)n * F + f;
-            const int pos = atomicAdd(&cursor[(size_t)b * N * F + seg], 1);
-            const int dst = offsets[(size_t)b * ((size_t)N * F + 1) + seg] + pos;
+            const int dst = offsets[(size_t)b * ((size_t)N * F + 1) + seg] + slotPos[e];
             entKey[dst] = m;
             entScale[dst] = weight ? weight[e] : 1.0f / (float)cnt;
         }
@@ -158,9 +159,8 @@ using namespace sph3d;
 // bytes of scratch the build itself needs (the in-degree / cursor array)
 extern "C" size_t sph3d_graph_transpose_workspace(int B, int N, int M, int K, int F)
 {
-    (void)M; (void)K;
     const size_t L = (size_t)N * F;
-    return sizeof(int) * ((size_t)B * L + (size_t)B * ((L + kChunk - 1) / kChunk));
+    return sizeof(int) * ((size_t)B * L + (size_t)B * ((L + kChunk - 1) / kChunk) + (size_t)B * M * K);
 }
 
 extern "C" int sph3d_graph_transpose(int B, int N, int M, int K, int F,
@@ -185,16 +185,18 @@ extern "C" int sph3d_graph_transpose(int B, int N, int M, int K, int F,
     const long long total = (long long)B * M * K;
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    if (total > 0)
-        hipLaunchKernelGGL(tg_count, dim3((unsigned)blocks), dim3(256), 0, st, B, N, M, K, F, nn_index, nn_count, bin_index, deg);
     const int L = N * F;
     const int chunks = (L + kChunk - 1) / kChunk;
     int* sums = deg + (size_t)B * L;
+    int* slot_pos = sums + (size_t)B * chunks;                      // [B*M*K] position of every edge inside its segment
+    if (total > 0)
+        hipLaunchKernelGGL(tg_count, dim3((unsigned)blocks), dim3(256), 0, st, B, N, M, K, F, nn_index, nn_count, bin_index, deg,
+                           slot_pos);
     hipLaunchKernelGGL(tg_chunk_sums, dim3(B * chunks), dim3(256), 0, st, L, chunks, deg, sums);
     hipLaunchKernelGGL(tg_scan_sums, dim3(B), dim3(256), 0, st, chunks, M * K, sums);
     hipLaunchKernelGGL(tg_apply, dim3(B * chunks), dim3(256), 0, st, L, chunks, deg, sums, offsets);
     if (total > 0)
         hipLaunchKernelGGL(tg_fill, dim3((unsigned)blocks), dim3(256), 0, st, B, N, M, K, F, nn_index, nn_count, bin_index,
-                           weight, offsets, deg, ent_key, ent_scale);
+                           weight, offsets, slot_pos, ent_key, ent_scale);
     return check_launch("sph3d_graph_transpose");
 }
