@@ -109,7 +109,15 @@ class GraphPlan:
                 s_fps.wait_stream(self.main)
                 s_graph.wait_stream(self.main)
             with torch.cuda.stream(s_fps):
+                # one contiguous copy of the coordinates for every op of the plan (the [:, :, 0:3] view made each
+                # neighbour search / binning / sampling call copy it again)
+                xyz = xyz.contiguous()
+                self.xyz_layers[0] = xyz
+                ev_xyz = torch.cuda.Event()
+                ev_xyz.record(s_fps)
                 self._sampling_chain(s_fps)
+            s_graph.wait_event(ev_xyz)
+            xyz.record_stream(s_graph)
             with torch.cuda.stream(s_graph):
                 self._build_all(s_graph)
         else:
