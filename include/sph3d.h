@@ -120,6 +120,7 @@ int sph3d_graph_transpose(int B, int N, int M, int K, int F,
                           const int* nn_index, const int* nn_count,
                           const int* bin_index /* or NULL */, const float* weight /* or NULL */,
                           int* offsets, int* ent_key, float* ent_scale,
+                          int* active_bins /* [F+1] or NULL: count, then the ascending list of the bins that occur */,
                           void* workspace, size_t workspace_bytes, sph3d_stream_t stream);
 /* conv gradients from a prebuilt transposed graph: both gradients in one pass, no float atomics
  * (grad_input gathered in registers; grad_filter accumulated in per-lane registers by persistent workgroups
@@ -129,6 +130,7 @@ size_t sph3d_depthwise_conv3d_grad_t_workspace(int B, int N, int F, int C, int r
 int sph3d_depthwise_conv3d_grad_t(int B, int N, int M, int F, int C, int r,
                                   const int* offsets, const int* ent_key, const float* ent_scale,
                                   const int* source_order /* optional [B,N] permutation per cloud: the order in which the sources are swept (NULL = index order) */,
+                                  const int* active_bins /* optional, from sph3d_graph_transpose: lets a graph with <= 17 occurring bins run with half the accumulator registers */,
                                   const float* input, const float* filter, const float* grad_output,
                                   float* grad_input, float* grad_filter,
                                   void* workspace, size_t workspace_bytes, sph3d_stream_t stream);

@@ -34,9 +34,9 @@ SIGNATURES = {
     "sph3d_avg_pool3d": (_I, [_I] * 5 + [_P] * 5),
     "sph3d_avg_pool3d_grad": (_I, [_I] * 5 + [_P] * 4 + [_P, _S, _P]),
     "sph3d_graph_transpose_workspace": (_S, [_I] * 5),
-    "sph3d_graph_transpose": (_I, [_I] * 5 + [_P] * 7 + [_P, _S, _P]),
+    "sph3d_graph_transpose": (_I, [_I] * 5 + [_P] * 8 + [_P, _S, _P]),
     "sph3d_depthwise_conv3d_grad_t_workspace": (_S, [_I] * 5),
-    "sph3d_depthwise_conv3d_grad_t": (_I, [_I] * 6 + [_P] * 9 + [_P, _S, _P]),
+    "sph3d_depthwise_conv3d_grad_t": (_I, [_I] * 6 + [_P] * 10 + [_P, _S, _P]),
     "sph3d_scatter_grad_t": (_I, [_I] * 4 + [_P] * 6),
     "sph3d_scatter_grad_workspace": (_S, [_I] * 4),
     "sph3d_mean_interpolate": (_I, [_I] * 5 + [_P] * 5),

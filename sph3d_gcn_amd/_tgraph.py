@@ -42,8 +42,9 @@ def source_order(nn_index):
 
 
 def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1):
-    """-> (offsets[B*(n_src*F+1)] i32, ent_key[B*M*K] i32, ent_scale[B*M*K] f32) on nn_index's device;
-    F = num_bins (the filter's bin count when bin_index is given, else 1)"""
+    """-> (offsets[B*(n_src*F+1)] i32, ent_key[B*M*K] i32, ent_scale[B*M*K] f32, active_bins[F+1] i32 | None) on
+    nn_index's device; F = num_bins (the filter's bin count when bin_index is given, else 1); active_bins (count, then
+    the bins that occur) is produced for binned graphs only"""
     F = int(num_bins) if bin_index is not None else 1
     key = (_ident(nn_index), _ident(nn_count), _ident(bin_index), _ident(weight), int(n_src), F, tuple(nn_index.shape))
     cur = torch.cuda.current_stream()
@@ -54,20 +55,22 @@ def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1
         if built_on != cur.cuda_stream:          # built ahead of time on the graph stream: order this stream after it
             cur.wait_event(ev)
             for t in out:
-                t.record_stream(cur)
+                if t is not None:
+                    t.record_stream(cur)
         return out
     B, M, K = nn_index.shape
     dev = nn_index.device
     offsets = torch.empty((B * (n_src * F + 1),), dtype=torch.int32, device=dev)
     ent_key = torch.empty((B * M * K,), dtype=torch.int32, device=dev)
     ent_scale = torch.empty((B * M * K,), dtype=torch.float32, device=dev)
+    active = torch.empty((F + 1,), dtype=torch.int32, device=dev) if bin_index is not None else None
     l = _lib.lib()
     wsb = l.sph3d_graph_transpose_workspace(B, n_src, M, K, F)
     ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
     _lib.check(l.sph3d_graph_transpose(B, n_src, M, K, F, _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(bin_index),
                                        _lib.ptr(weight), _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale),
-                                       _lib.ptr(ws), wsb, _lib.stream_ptr()))
-    out = (offsets, ent_key, ent_scale)
+                                       _lib.ptr(active), _lib.ptr(ws), wsb, _lib.stream_ptr()))
+    out = (offsets, ent_key, ent_scale, active)
     ev = torch.cuda.Event()
     ev.record(cur)
     _cache[key] = (out, (nn_index, nn_count, bin_index, weight), ev, cur.cuda_stream)

@@ -354,11 +354,16 @@ constexpr int kBwdTPointsPerWG = 64;     // measured: 256 -> 1.90 ms, 128 -> 1.1
 // HALF (CR == 128, V == 4): a grad_out row is 32 lanes wide, so the two halves of the wave take ALTERNATE edges of
 // a segment (one wave load = two rows) and keep separate partial sums, added across the halves once per source
 // (grad_input) / once per launch (the filter accumulators).
-template <int R, int V, int MAXF, bool HALF>
-__global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
+// COMPACT: the accumulator table has one row per ACTIVE bin of the graph (active_bins = [count, ascending list], written by
+// sph3d_graph_transpose): with the reference's sqrt-distance quirk the inner radial shell is empty at small radii
+// (SURVEY §0.5), so at S3DIS levels 0-2 only 17 of the 33 bins ever occur: 68 accumulator VGPRs instead of 132, four
+// workgroups per CU instead of three, and a 17- instead of 33-iteration segment loop.  The host cannot know the count
+// without a device->host sync, so BOTH variants are launched and each returns at once unless the count is in its range.
+template <int R, int V, int MAXF, bool HALF, bool COMPACT>
+__global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t_vec(
     int B, int N, int M, int F, int C, int W, int parts, int nslices,
     const int* __restrict__ offsets, const int* __restrict__ entKey, const float* __restrict__ entScale,
-    const int* __restrict__ order,
+    const int* __restrict__ order, const int* __restrict__ activeBins, int compactMax,
     const float* __restrict__ input, const float* __restrict__ filter, const float* __restrict__ gradOutput,
     float* __restrict__ gradInput, float* __restrict__ partial)
 {
@@ -366,7 +371,10 @@ __global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
     constexpr int SLW = 64 * V;                 // slice width in output channels
     constexpr int VI = (V >= R) ? V / R : 1;    // input channels per lane
     const int CR = C * R;
-    // persistent workgroups: W per XCD and channel slice, all resident together (launch bounds: 3 per CU)
+    // which of the two launches does the work (wave-uniform, decided from device memory: no host sync)
+    const int A = activeBins ? uniform(activeBins[0]) : F;
+    if (COMPACT ? (A > MAXF) : (activeBins != nullptr && A <= compactMax)) return;
+    // persistent workgroups: W per XCD and channel slice, all resident together (launch bounds: 3 or 4 per CU)
     const int xcd = (int)blockIdx.x & 7;
     const int q = (int)blockIdx.x >> 3;
     const int slice = q / W;
@@ -424,10 +432,14 @@ __global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
 #pragma unroll
         for (int v = 0; v < V; v++) gi[v] = 0.f;
 #pragma unroll
-        for (int f = 0; f < MAXF; f++) {
-            if (f < F) {
-                const int e0 = __builtin_amdgcn_readlane(f < 64 ? ov0 : ov1, f & 63);
-                const int e1 = __builtin_amdgcn_readlane((f + 1) < 64 ? ov0 : ov1, (f + 1) & 63);
+        for (int fi = 0; fi < MAXF; fi++) {
+            if (fi < (COMPACT ? A : F)) {
+                // COMPACT: row fi of the accumulators belongs to bin activeBins[1 + fi] (wave-uniform, F <= 63)
+                const int f = COMPACT ? uniform(activeBins[1 + fi]) : fi;
+                const int e0 = COMPACT ? __builtin_amdgcn_readlane(ov0, f)
+                                       : __builtin_amdgcn_readlane(fi < 64 ? ov0 : ov1, fi & 63);
+                const int e1 = COMPACT ? __builtin_amdgcn_readlane(ov0, f + 1)
+                                       : __builtin_amdgcn_readlane((fi + 1) < 64 ? ov0 : ov1, (fi + 1) & 63);
                 if (e0 < e1) {                               // wave-uniform: most (n, bin) segments are empty or short
                     float sg[V];
 #pragma unroll
@@ -492,7 +504,7 @@ __global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
 #pragma unroll
                     for (int v = 0; v < V; v++) {
                         gi[v] = fmaf(sg[v], wrow[v], gi[v]);
-                        acc[f][v] = fmaf(sg[v], xv[v], acc[f][v]);
+                        acc[fi][v] = fmaf(sg[v], xv[v], acc[fi][v]);
                     }
                 }
             }
@@ -526,15 +538,20 @@ __global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
     // workgroup reduction of the per-wave accumulators: waves take turns on one [F][SL] LDS table
     __syncthreads();                 // everyone is done reading lfilt
     float* tab = lds;                // reuse: [F][SL]
+    if (COMPACT) {                   // rows of bins that never occur stay zero
+        for (int e = threadIdx.x; e < F * SL; e += blockDim.x) tab[e] = 0.f;
+        __syncthreads();
+    }
     for (int w = 0; w < kBwdTWaves; w++) {
         if (wave == w && act && half == 0) {
 #pragma unroll
             for (int i = 0; i < MAXF; i++) {
-                if (i < F) {
+                if (i < (COMPACT ? A : F)) {
+                    const int f = COMPACT ? uniform(activeBins[1 + i]) : i;
 #pragma unroll
                     for (int v = 0; v < V; v++) {
-                        float* p = &tab[i * SL + cl0 + v];
-                        *p = (w == 0) ? acc[i][v] : (*p + acc[i][v]);
+                        float* p = &tab[f * SL + cl0 + v];
+                        *p = (w == 0 && !COMPACT) ? acc[i][v] : (*p + acc[i][v]);
                     }
                 }
             }
@@ -552,8 +569,10 @@ __global__ __launch_bounds__(kBwdTWaves * 64, 3) void dwconv_bwd_t_vec(
 // grad_filter[j] = sum over the B*nblocks partial tables, fixed order -> deterministic given the partials.
 // 1024 threads = 32 outputs x 32 partial-lanes (a one-thread-per-output loop over ~1000 slabs is latency-bound; 8 lanes: 20-30 us).
 __global__ __launch_bounds__(1024) void reduce_filter_partials(int nparts, int total, const float* __restrict__ partial,
-                                                              float* __restrict__ gradFilter)
+                                                              float* __restrict__ gradFilter,
+                                                              const int* __restrict__ activeBins, int compactMax, int npartsCompact)
 {
+    if (activeBins != nullptr && activeBins[0] <= compactMax) nparts = npartsCompact;   // the compact launch wrote the slabs
     __shared__ float red[32][32];      // 32 outputs x 32 partial-lanes
     const int cx = (int)threadIdx.x & 31, py = (int)threadIdx.x >> 5;
     const int j = blockIdx.x * 32 + cx;
@@ -701,13 +720,13 @@ extern "C" int sph3d_depthwise_conv3d(int B, int N, int M, int F, int C, int r, 
 
 // layout of the transposed graph inside a caller-provided workspace
 struct TGraphWs {
-    int* offsets; int* key; float* scale; void* scratch; size_t scratch_bytes;
+    int* offsets; int* key; float* scale; int* active; void* scratch; size_t scratch_bytes;
 };
 static size_t tgraph_ws_bytes(int B, int N, int M, int K, int F)
 {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     return al(sizeof(int) * (size_t)B * ((size_t)N * F + 1)) + 2 * al(sizeof(int) * (size_t)B * M * K) +
-           al(sph3d_graph_transpose_workspace(B, N, M, K, F));
+           al(sizeof(int) * ((size_t)F + 1)) + al(sph3d_graph_transpose_workspace(B, N, M, K, F));
 }
 static TGraphWs tgraph_carve(void* ws, int B, int N, int M, int K, int F)
 {
@@ -717,6 +736,7 @@ static TGraphWs tgraph_carve(void* ws, int B, int N, int M, int K, int F)
     t.offsets = (int*)p; p += al(sizeof(int) * (size_t)B * ((size_t)N * F + 1));
     t.key = (int*)p; p += al(sizeof(int) * (size_t)B * M * K);
     t.scale = (float*)p; p += al(sizeof(int) * (size_t)B * M * K);
+    t.active = (int*)p; p += al(sizeof(int) * ((size_t)F + 1));
     t.scratch = p; t.scratch_bytes = al(sph3d_graph_transpose_workspace(B, N, M, K, F));
     return t;
 }
@@ -742,7 +762,7 @@ static int vec_plan(int F, int CR, int r, int& V)
 //   * small levels (N = 128..768: the whole launch is a few hundred sources per XCD): the kernel is a chain of
 //     dependent gathers per source, so the sources are spread over enough workgroups to put two on every CU
 //     (down to 2 sources per wave) instead of leaving most CUs idle.
-static void bwd_plan(int B, int N, int nslices, int& parts, int& W)
+static void bwd_plan(int B, int N, int nslices, int wg_per_cu, int& parts, int& W)
 {
     int g = B & 7;                         // gcd(B, 8)
     g = g == 0 ? 8 : (g & -g);
@@ -756,7 +776,8 @@ static void bwd_plan(int B, int N, int nslices, int& parts, int& W)
     const long long w_min = (src + 2 * kBwdTWaves - 1) / (2 * kBwdTWaves);
     long long w = w_fill < w_min ? w_fill : w_min;
     if (w < w_work) w = w_work;
-    W = (int)(w < 1 ? 1 : (w > 96 ? 96 : w));
+    const long long cap = 32LL * wg_per_cu;
+    W = (int)(w < 1 ? 1 : (w > cap ? cap : w));
 }
 
 static int bwd_slices(int F, int CR, int r)
@@ -771,41 +792,57 @@ extern "C" size_t sph3d_depthwise_conv3d_grad_t_workspace(int B, int N, int F, i
     int V = 0;
     if (!vec_plan(F, C * r, r, V)) return 0;
     int parts, W;
-    bwd_plan(B, N, bwd_slices(F, C * r, r), parts, W);
+    bwd_plan(B, N, bwd_slices(F, C * r, r), 4, parts, W);      // sized for the compact variant (4 workgroups per CU)
     return sizeof(float) * (size_t)8 * W * F * C * r;
 }
 
+constexpr int kCompactBins = 17;     // accumulator rows of the compact variant
+
 template <int R, int V, int MAXF, bool HALF>
 static int launch_bwd_t_vec(int B, int N, int M, int F, int C, const int* offsets, const int* ent_key,
-                            const float* ent_scale, const int* order, const float* input, const float* filter,
-                            const float* grad_output, float* grad_input, float* grad_filter, float* partial,
-                            hipStream_t st)
+                            const float* ent_scale, const int* order, const int* active_bins, const float* input,
+                            const float* filter, const float* grad_output, float* grad_input, float* grad_filter,
+                            float* partial, hipStream_t st)
 {
     const int CR = C * R;
     const int SLW = 64 * V;
     const int nslices = (CR + SLW - 1) / SLW;
-    int parts, W;
-    bwd_plan(B, N, nslices, parts, W);
+    int parts, W, Wc = 0;
+    bwd_plan(B, N, nslices, 3, parts, W);
     const int SLmax = CR < SLW ? CR : SLW;
     const size_t lds = (size_t)F * SLmax * sizeof(float);
-    auto kern = dwconv_bwd_t_vec<R, V, MAXF, HALF>;
+    // the compact launch exists for the 4-channels-per-lane plans with at most 63 bins (one register of segment bounds)
+    const bool compact = active_bins != nullptr && V == 4 && MAXF > kCompactBins && F <= 63;
+    auto kern = dwconv_bwd_t_vec<R, V, MAXF, HALF, false>;
+    auto kernc = dwconv_bwd_t_vec<R, V, (V == 4 ? kCompactBins : MAXF), HALF, (V == 4)>;
     if (lds > 64 * 1024) {
         int rc = check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                            "conv3d: hipFuncSetAttribute");
         if (rc) return rc;
+        rc = check_hip(hipFuncSetAttribute((const void*)kernc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                       "conv3d: hipFuncSetAttribute");
+        if (rc) return rc;
+    }
+    const int* ab = compact ? active_bins : nullptr;
+    if (compact) {
+        int pc;
+        bwd_plan(B, N, nslices, 4, pc, Wc);
+        hipLaunchKernelGGL(kernc, dim3(8 * Wc * nslices), dim3(kBwdTWaves * 64), lds, st, B, N, M, F, C,
+                           Wc, pc, nslices, offsets, ent_key, ent_scale, order, ab, kCompactBins, input, filter, grad_output,
+                           grad_input, partial);
     }
     hipLaunchKernelGGL(kern, dim3(8 * W * nslices), dim3(kBwdTWaves * 64), lds, st, B, N, M, F, C,
-                       W, parts, nslices, offsets, ent_key, ent_scale, order, input, filter, grad_output, grad_input,
-                       partial);
+                       W, parts, nslices, offsets, ent_key, ent_scale, order, ab, kCompactBins, input, filter, grad_output,
+                       grad_input, partial);
     const int total = F * CR;
     hipLaunchKernelGGL(reduce_filter_partials, dim3((total + 31) / 32), dim3(1024), 0, st, 8 * W, total, partial,
-                       grad_filter);
+                       grad_filter, ab, kCompactBins, 8 * Wc);
     return check_launch("sph3d_depthwise_conv3d_grad_t");
 }
 
 extern "C" int sph3d_depthwise_conv3d_grad_t(int B, int N, int M, int F, int C, int r,
                                              const int* offsets, const int* ent_key, const float* ent_scale,
-                                             const int* source_order,
+                                             const int* source_order, const int* active_bins,
                                              const float* input, const float* filter, const float* grad_output,
                                              float* grad_input, float* grad_filter,
                                              void* workspace, size_t workspace_bytes, sph3d_stream_t stream)
@@ -824,14 +861,14 @@ extern "C" int sph3d_depthwise_conv3d_grad_t(int B, int N, int M, int F, int C, 
         }
         float* partial = (float*)workspace;
 #define SPH3D_GO(RR, VV, MF) \
-    return launch_bwd_t_vec<RR, VV, MF, false>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, input, filter, \
-                                        grad_output, grad_input, grad_filter, partial, st)
+    return launch_bwd_t_vec<RR, VV, MF, false>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, active_bins, input, \
+                                        filter, grad_output, grad_input, grad_filter, partial, st)
         if (V == 4 && CR == 128 && r == 2)
-            return launch_bwd_t_vec<2, 4, 33, true>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, input, filter,
-                                                    grad_output, grad_input, grad_filter, partial, st);
+            return launch_bwd_t_vec<2, 4, 33, true>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, active_bins, input,
+                                                    filter, grad_output, grad_input, grad_filter, partial, st);
         if (V == 4 && CR == 128 && r == 1)
-            return launch_bwd_t_vec<1, 4, 33, true>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, input, filter,
-                                                    grad_output, grad_input, grad_filter, partial, st);
+            return launch_bwd_t_vec<1, 4, 33, true>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, active_bins, input,
+                                                    filter, grad_output, grad_input, grad_filter, partial, st);
         if (V == 4 && r == 2) SPH3D_GO(2, 4, 33);
         if (V == 4 && r == 1) SPH3D_GO(1, 4, 33);
         if (V == 2 && r == 2) SPH3D_GO(2, 2, 65);
@@ -873,12 +910,12 @@ extern "C" int sph3d_depthwise_conv3d_grad(int B, int N, int M, int F, int C, in
         set_error("DepthwiseConv3dGrad: workspace %zu B < required %zu B", workspace_bytes, need);
         return SPH3D_EWORKSPACE;
     }
-    if (B == 0) return sph3d_depthwise_conv3d_grad_t(B, N, M, F, C, r, nullptr, nullptr, nullptr, nullptr, input, filter,
+    if (B == 0) return sph3d_depthwise_conv3d_grad_t(B, N, M, F, C, r, nullptr, nullptr, nullptr, nullptr, nullptr, input, filter,
                                                      grad_output, grad_input, grad_filter, nullptr, 0, stream);
     TGraphWs t = tgraph_carve(workspace, B, N, M, K, F);
-    rc = sph3d_graph_transpose(B, N, M, K, F, nn_index, nn_count, bin_index, nullptr, t.offsets, t.key, t.scale,
+    rc = sph3d_graph_transpose(B, N, M, K, F, nn_index, nn_count, bin_index, nullptr, t.offsets, t.key, t.scale, t.active,
                                t.scratch, t.scratch_bytes, stream);
     if (rc) return rc;
-    return sph3d_depthwise_conv3d_grad_t(B, N, M, F, C, r, t.offsets, t.key, t.scale, nullptr, input, filter, grad_output,
+    return sph3d_depthwise_conv3d_grad_t(B, N, M, F, C, r, t.offsets, t.key, t.scale, nullptr, t.active, input, filter, grad_output,
                                          grad_input, grad_filter, (char*)workspace + tg, workspace_bytes - tg, stream);
 }

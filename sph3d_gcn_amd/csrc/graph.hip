@@ -24,7 +24,7 @@ namespace sph3d {
 
 __global__ __launch_bounds__(256) void tg_count(int B, int N, int M, int K, int F, const int* __restrict__ nnIndex,
                                                 const int* __restrict__ nnCount, const int* __restrict__ binIndex,
-                                                int* __restrict__ deg, int* __restrict__ slotPos)
+                                                int* __restrict__ deg, int* __restrict__ slotPos, int* __restrict__ binUsed)
 {
     const long long total = (long long)B * M * K;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void tg_count(int B, int N, int M, int K, int 
             // the value the atomic returns is the edge's position inside its segment: kept, so that the fill pass needs
             // no second round of atomics (measured: count 0.25 + fill 0.32 ms -> see DESIGN.md)
             slotPos[e] = atomicAdd(&deg[((size_t)b * N + nnIndex[e]) * F + f], 1);
+            if (binUsed) binUsed[f] = 1;          // benign race: every writer stores 1
         }
     }
 }
@@ -126,6 +127,22 @@ __global__ __launch_bounds__(256) void tg_apply(int L, int chunks, int* __restri
     if (c == chunks - 1 && threadIdx.x == 255) off[L] = run;     // end of the cloud's last segment
 }
 
+// active_bins = [count, ascending list of the bins that occur anywhere in the graph] (conv gradient, compact variant)
+__global__ __launch_bounds__(256) void tg_active_bins(int F, const int* __restrict__ binUsed, int* __restrict__ active)
+{
+    __shared__ int lds[256];
+    int run = 0;
+    for (int base = 0; base < F; base += 256) {
+        const int f = base + (int)threadIdx.x;
+        const int u = (f < F && binUsed[f] != 0) ? 1 : 0;
+        int total;
+        const int ex = block_exclusive_scan_256(u, lds, total);
+        if (u) active[1 + run + ex] = f;
+        run += total;
+    }
+    if (threadIdx.x == 0) active[0] = run;
+}
+
 __global__ __launch_bounds__(256) void tg_fill(int B, int N, int M, int K, int F, const int* __restrict__ nnIndex,
                                                const int* __restrict__ nnCount, const int* __restrict__ binIndex,
                                                const float* __restrict__ weight, const int* __restrict__ offsets,
@@ -160,12 +177,12 @@ using namespace sph3d;
 extern "C" size_t sph3d_graph_transpose_workspace(int B, int N, int M, int K, int F)
 {
     const size_t L = (size_t)N * F;
-    return sizeof(int) * ((size_t)B * L + (size_t)B * ((L + kChunk - 1) / kChunk) + (size_t)B * M * K);
+    return sizeof(int) * ((size_t)B * L + (size_t)F + (size_t)B * ((L + kChunk - 1) / kChunk) + (size_t)B * M * K);
 }
 
 extern "C" int sph3d_graph_transpose(int B, int N, int M, int K, int F,
                                      const int* nn_index, const int* nn_count, const int* bin_index,
-                                     const float* weight, int* offsets, int* ent_key, float* ent_scale,
+                                     const float* weight, int* offsets, int* ent_key, float* ent_scale, int* active_bins,
                                      void* workspace, size_t workspace_bytes, sph3d_stream_t stream)
 {
     SPH3D_REQUIRE(B >= 0 && N > 0 && M >= 0 && K > 0, "graph_transpose: bad dims B=%d N=%d M=%d K=%d", B, N, M, K);
@@ -180,18 +197,20 @@ extern "C" int sph3d_graph_transpose(int B, int N, int M, int K, int F,
     }
     hipStream_t st = as_stream(stream);
     int* deg = (int*)workspace;
-    int rc = check_hip(hipMemsetAsync(deg, 0, sizeof(int) * (size_t)B * N * F, st), "graph_transpose: memset");
+    int rc = check_hip(hipMemsetAsync(deg, 0, sizeof(int) * ((size_t)B * N * F + F), st), "graph_transpose: memset");
     if (rc) return rc;
     const long long total = (long long)B * M * K;
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     const int L = N * F;
     const int chunks = (L + kChunk - 1) / kChunk;
-    int* sums = deg + (size_t)B * L;
+    int* bin_used = deg + (size_t)B * L;                            // [F] flags, zeroed with the counters
+    int* sums = bin_used + F;
     int* slot_pos = sums + (size_t)B * chunks;                      // [B*M*K] position of every edge inside its segment
     if (total > 0)
         hipLaunchKernelGGL(tg_count, dim3((unsigned)blocks), dim3(256), 0, st, B, N, M, K, F, nn_index, nn_count, bin_index, deg,
-                           slot_pos);
+                           slot_pos, active_bins ? bin_used : nullptr);
+    if (active_bins) hipLaunchKernelGGL(tg_active_bins, dim3(1), dim3(256), 0, st, F, bin_used, active_bins);
     hipLaunchKernelGGL(tg_chunk_sums, dim3(B * chunks), dim3(256), 0, st, L, chunks, deg, sums);
     hipLaunchKernelGGL(tg_scan_sums, dim3(B), dim3(256), 0, st, chunks, M * K, sums);
     hipLaunchKernelGGL(tg_apply, dim3(B * chunks), dim3(256), 0, st, L, chunks, deg, sums, offsets);

@@ -259,7 +259,7 @@ static int grad_via_transpose(const char* who, int B, int Nin, int Mout, int C, 
     int* offsets = (int*)p; p += al(sizeof(int) * (size_t)B * (Nin + 1));
     int* key = (int*)p; p += al(sizeof(int) * (size_t)B * Mout * K);
     float* scale = (float*)p; p += al(sizeof(int) * (size_t)B * Mout * K);
-    int rc = sph3d_graph_transpose(B, Nin, Mout, K, 1, nn_index, nn_count, nullptr, weight, offsets, key, scale, p,
+    int rc = sph3d_graph_transpose(B, Nin, Mout, K, 1, nn_index, nn_count, nullptr, weight, offsets, key, scale, nullptr, p,
                                    al(sph3d_graph_transpose_workspace(B, Nin, Mout, K, 1)), stream);
     if (rc) return rc;
     return launch_bwd_t(who, B, Nin, Mout, C, offsets, key, scale, grad_output, grad_input, as_stream(stream));

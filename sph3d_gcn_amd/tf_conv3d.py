@@ -62,13 +62,13 @@ def _depthwise_conv3d_grad_impl(input: torch.Tensor, filter: torch.Tensor, grad_
     grad_input = torch.empty_like(input)
     grad_filter = torch.empty_like(filter)
     # gather over the transposed graph (built once per graph, shared by every gradient that uses it)
-    offsets, ent_key, ent_scale = _tgraph.transpose(nn_index, nn_count, N, bin_index=bin_index, num_bins=F)
+    offsets, ent_key, ent_scale, active = _tgraph.transpose(nn_index, nn_count, N, bin_index=bin_index, num_bins=F)
     l = _lib.lib()
     wsb = l.sph3d_depthwise_conv3d_grad_t_workspace(B, N, F, C, r)
     ws = torch.empty((wsb,), dtype=torch.uint8, device=input.device) if wsb else None
     _lib.check(l.sph3d_depthwise_conv3d_grad_t(
         B, N, M, F, C, r, _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale),
-        _lib.ptr(_tgraph.source_order(nn_index)),
+        _lib.ptr(_tgraph.source_order(nn_index)), _lib.ptr(active),
         _lib.ptr(input), _lib.ptr(filter), _lib.ptr(grad_output), _lib.ptr(grad_input), _lib.ptr(grad_filter),
         _lib.ptr(ws), wsb, _lib.stream_ptr()))
     return grad_input, grad_filter

@@ -100,7 +100,7 @@ def _avg_pool3d_grad_impl(input: torch.Tensor, grad_output: torch.Tensor, nn_ind
     B, N, C = input.shape
     M, K = nn_index.shape[1], nn_index.shape[2]
     grad_input = torch.empty((B, N, C), dtype=torch.float32, device=input.device)
-    offsets, ent_key, ent_scale = _tgraph.transpose(nn_index, nn_count, N)
+    offsets, ent_key, ent_scale, _ = _tgraph.transpose(nn_index, nn_count, N)
     _lib.check(_lib.lib().sph3d_scatter_grad_t(B, N, M, C, _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale),
                                                _lib.ptr(grad_output), _lib.ptr(grad_input), _lib.stream_ptr()))
     return grad_input

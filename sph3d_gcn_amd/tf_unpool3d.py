@@ -44,7 +44,7 @@ def _mean_interpolate_grad_impl(input: torch.Tensor, grad_output: torch.Tensor, 
     B, M, C = input.shape
     N, K = nn_index.shape[1], nn_index.shape[2]
     grad_input = torch.empty((B, M, C), dtype=torch.float32, device=input.device)
-    offsets, ent_key, ent_scale = _tgraph.transpose(nn_index, nn_count, M)      # source points = the M coarse points
+    offsets, ent_key, ent_scale, _ = _tgraph.transpose(nn_index, nn_count, M)   # source points = the M coarse points
     _lib.check(_lib.lib().sph3d_scatter_grad_t(B, M, N, C, _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale),
                                                _lib.ptr(grad_output), _lib.ptr(grad_input), _lib.stream_ptr()))
     return grad_input
@@ -101,7 +101,7 @@ def _weighted_interpolate_grad_impl(input: torch.Tensor, grad_output: torch.Tens
     B, M, C = input.shape
     N, K = nn_index.shape[1], nn_index.shape[2]
     grad_input = torch.empty((B, M, C), dtype=torch.float32, device=input.device)
-    offsets, ent_key, ent_scale = _tgraph.transpose(nn_index, nn_count, M, weight=weight)
+    offsets, ent_key, ent_scale, _ = _tgraph.transpose(nn_index, nn_count, M, weight=weight)
     _lib.check(_lib.lib().sph3d_scatter_grad_t(B, M, N, C, _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale),
                                                _lib.ptr(grad_output), _lib.ptr(grad_input), _lib.stream_ptr()))
     return grad_input

@@ -131,6 +131,31 @@ def _graph(kind, B, N, M, K, radius, seed):
     return db, q, idx, cnt, dst, filt
 
 
+@pytest.mark.parametrize("C,r", [(64, 2), (128, 2), (32, 1), (256, 2)])
+@pytest.mark.parametrize("nbins", [5, 17, 18, 33])
+def test_conv_grad_all_bins_and_compact_bins(dev, C, r, nbins):
+    """The gradient kernel has two launches: a compact one for graphs in which at most 17 of the bins occur (the usual
+    case under the sqrt-distance quirk) and the full 33-bin one; the choice is made on the device.  Synthetic bin ids
+    drawn from `nbins` distinct values exercise both, and the 17 / 18 boundary."""
+    B, N, K = 2, 300, 24
+    rng = np.random.RandomState(1000 * nbins + C + r)
+    db, q, idx, cnt, dst, _ = _graph("uniform", B, N, None, K, 0.2, seed=nbins)
+    allowed = np.sort(rng.permutation(33)[:nbins]).astype(np.int32)
+    filt = allowed[rng.randint(0, nbins, size=idx.shape)].astype(np.int32)
+    filt[np.arange(K)[None, None, :] >= cnt[:, :, None]] = 0       # unused slots read 0, as the op writes them
+    x = rng.randn(B, N, C).astype(np.float32)
+    w = rng.randn(33, C, r).astype(np.float32)
+    go = rng.randn(B, N, C * r).astype(np.float32)
+    gi_o, gf_o = oracle.depthwise_conv3d_grad(x, w, go, idx, cnt, filt)
+    gi, gf = tf_conv3d.depthwise_conv3d_grad(_t(x, dev), _t(w, dev), _t(go, dev), _t(idx, dev), _t(cnt, dev), _t(filt, dev))
+    np.testing.assert_allclose(_n(gi), gi_o, **TOL)
+    s_ = max(1.0, float(np.abs(gf_o).max()))
+    np.testing.assert_allclose(_n(gf) / s_, gf_o / s_, **TOL)
+    used = np.unique(filt[np.arange(K)[None, None, :] < cnt[:, :, None]])
+    unused = np.setdiff1d(np.arange(33), used)
+    assert (_n(gf)[unused] == 0).all()                            # bins that never occur get an exact zero gradient
+
+
 # (B, N, M, C, r, K)
 CONV_CASES = [(2, 200, 100, 8, 2, 16), (1, 64, 64, 3, 1, 8), (2, 300, 300, 35, 2, 32), (2, 256, 256, 67, 1, 64),
               (2, 500, 500, 64, 2, 64), (1, 300, 150, 128, 2, 64), (1, 128, 128, 1024, 2, 64), (2, 200, 200, 131, 1, 16),

@@ -8,7 +8,7 @@ B,N,K=16,8192,64
 xyz=torch.from_numpy(synth.s3dis_batch(1000,B,N)[0]).to(dev)
 idx,cnt,dst=tf_nnquery.build_sphere_neighbor(xyz,xyz,0.1,None,K)
 filt=tf_buildkernel.spherical_kernel(xyz,xyz,idx,cnt,dst,0.1,[8,2,2])
-off,key,sc=_tgraph.transpose(idx,cnt,N,bin_index=filt,num_bins=33)
+off,key,sc,_=_tgraph.transpose(idx,cnt,N,bin_index=filt,num_bins=33)
 o=off.view(B,N*33+1).cpu().numpy()
 seg=np.diff(o,axis=1).reshape(B,N,33)
 print("segment length histogram (fraction):", np.bincount(seg.ravel(),minlength=10)[:12]/seg.size)

@@ -11,7 +11,7 @@ filt=tf_buildkernel.spherical_kernel(xyz,xyz,idx,cnt,dst,0.1,[8,2,2])
 def run():
     _tgraph.clear()
     return _tgraph.transpose(idx,cnt,N,bin_index=filt,num_bins=33)
-off,key,sc=run(); torch.cuda.synchronize()
+off,key,sc,act=run(); torch.cuda.synchronize(); print('active bins', act.cpu().numpy().tolist())
 import numpy as np
 o=off.view(B,N*33+1).cpu().numpy()
 deg=np.diff(o,axis=1)
