@@ -44,19 +44,33 @@ __global__ __launch_bounds__(256) void norm_reduce_kernel(int R, int C, const fl
         rs = *reinterpret_cast<const float4*>(&rstd[tx * 4]);
     }
     if (act) {
-        for (int r = r0 + ty; r < r1; r += rows_per_iter) {
-            const float4 v = *reinterpret_cast<const float4*>(&y[(size_t)r * C + tx * 4]);
-            const float4 z = make_float4(elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w));
-            if (!BWD) {
-                a.x += z.x; a.y += z.y; a.z += z.z; a.w += z.w;
-                b.x = fmaf(z.x, z.x, b.x); b.y = fmaf(z.y, z.y, b.y); b.z = fmaf(z.z, z.z, b.z); b.w = fmaf(z.w, z.w, b.w);
-            } else {
-                const float4 g = *reinterpret_cast<const float4*>(&dout[(size_t)r * C + tx * 4]);
-                a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
-                b.x = fmaf(g.x, (z.x - mu.x) * rs.x, b.x);
-                b.y = fmaf(g.y, (z.y - mu.y) * rs.y, b.y);
-                b.z = fmaf(g.z, (z.z - mu.z) * rs.z, b.z);
-                b.w = fmaf(g.w, (z.w - mu.w) * rs.w, b.w);
+        // four rows per trip, their loads issued together: with one row per trip the kernel ran at a third of the HBM
+        // rate (one or two 16-B loads in flight per lane)
+        constexpr int UN = 4;
+        for (int rb = r0 + ty; rb < r1; rb += UN * rows_per_iter) {
+            float4 v[UN], g[UN];
+#pragma unroll
+            for (int u = 0; u < UN; u++) {
+                const int r = rb + u * rows_per_iter;
+                const int rc = r < r1 ? r : rb;                      // clamped: re-reads the trip's first row
+                v[u] = *reinterpret_cast<const float4*>(&y[(size_t)rc * C + tx * 4]);
+                if (BWD) g[u] = *reinterpret_cast<const float4*>(&dout[(size_t)rc * C + tx * 4]);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; u++) {
+                if (rb + u * rows_per_iter < r1) {
+                    const float4 z = make_float4(elu1(v[u].x), elu1(v[u].y), elu1(v[u].z), elu1(v[u].w));
+                    if (!BWD) {
+                        a.x += z.x; a.y += z.y; a.z += z.z; a.w += z.w;
+                        b.x = fmaf(z.x, z.x, b.x); b.y = fmaf(z.y, z.y, b.y); b.z = fmaf(z.z, z.z, b.z); b.w = fmaf(z.w, z.w, b.w);
+                    } else {
+                        a.x += g[u].x; a.y += g[u].y; a.z += g[u].z; a.w += g[u].w;
+                        b.x = fmaf(g[u].x, (z.x - mu.x) * rs.x, b.x);
+                        b.y = fmaf(g[u].y, (z.y - mu.y) * rs.y, b.y);
+                        b.z = fmaf(g[u].z, (z.z - mu.z) * rs.z, b.z);
+                        b.w = fmaf(g[u].w, (z.w - mu.w) * rs.w, b.w);
+                    }
+                }
             }
         }
     }
@@ -190,7 +204,8 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(long long total4, int C
     }
 }
 
-static int norm_blocks(int R) { int b = (R + 127) / 128; return b < 1 ? 1 : (b > kNormMaxBlocks ? kNormMaxBlocks : b); }
+// one workgroup per ~32 rows (the small levels have only a few thousand rows: 128-row blocks left most CUs idle)
+static int norm_blocks(int R) { int b = (R + 31) / 32; return b < 1 ? 1 : (b > kNormMaxBlocks ? kNormMaxBlocks : b); }
 
 }  // namespace sph3d
 
