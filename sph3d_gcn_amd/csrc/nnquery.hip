@@ -21,6 +21,8 @@
 
 namespace sph3d {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int kWavesPerWG = 16;
 constexpr int kMaxChunk = 12288;   // points per LDS chunk (3 * 12288 * 4 B = 144 KB)
 
@@ -138,36 +140,48 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
                     stage_cloud(dbi, c0, cn, chunkN, lds);
                     __syncthreads();
                 }
-                for (int base = 0; base < cn; base += 64) {
+                // two strips (128 database points) per trip, the pair of distances in one packed register: the subtractions,
+                // products and sums are v_pk_{add,mul}_f32 (IEEE per component, no contraction: the same roundings as the scalar
+                // form), so the arithmetic of a trip costs what one strip cost before
+                for (int base = 0; base < cn; base += 128) {
                     bool open = false;   // some chain still has free slots
 #pragma unroll
                     for (int c = 0; c < CPW; c++) open = open || (has[c] && s[c] < K);
                     if (!open) break;
-                    const int k = base + lane;
-                    const bool inb = k < cn;
-                    const int kk = inb ? k : cn - 1;
-                    const float x = lx[kk], y = ly[kk], z = lz[kk];
+                    const int k0 = base + lane, k1 = k0 + 64;
+                    const bool in0 = k0 < cn, in1 = k1 < cn;
+                    const int kk0 = in0 ? k0 : cn - 1, kk1 = in1 ? k1 : cn - 1;
+                    const f32x2 x = {lx[kk0], lx[kk1]}, y = {ly[kk0], ly[kk1]}, z = {lz[kk0], lz[kk1]};
 #pragma unroll
                     for (int c = 0; c < CPW; c++) {
                         if (has[c] && s[c] < K) {   // wave-uniform
-                            const float dx = x - qx[c];
-                            const float dy = y - qy[c];
-                            const float dz = z - qz[c];
-                            const float d2 = (dx * dx + dy * dy) + dz * dz;   // tf_nnquery_gpu.cu:45-46
-                            const bool hit = inb && (d2 < thr[c]);
-                            const unsigned long long mask = __ballot(hit);
-                            if (mask != 0ull) {
-                                const int pos = s[c] + prefix_popc(mask);
-                                if (hit && pos < K) {
-                                    if (DEFER) {
-                                        lhits[(wave * CPW + c) * K + pos] = c0 + k;
-                                    } else {
-                                        const size_t o = ((size_t)i * M + j[c]) * K + pos;
-                                        nnIndex[o] = c0 + k;
-                                        nnDist[o] = sqrtf(sqrtf(d2));   // :47 then :54 — sqrt of the distance
+                            const f32x2 dx = x - qx[c];
+                            const f32x2 dy = y - qy[c];
+                            const f32x2 dz = z - qz[c];
+                            const f32x2 d2 = (dx * dx + dy * dy) + dz * dz;   // tf_nnquery_gpu.cu:45-46
+                            const bool hit0 = in0 && (d2.x < thr[c]);
+                            const bool hit1 = in1 && (d2.y < thr[c]);
+                            const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
+                            if ((m0 | m1) != 0ull) {
+                                // ascending index: the first strip's hits take their slots before the second strip's
+                                const int pos0 = s[c] + prefix_popc(m0);
+                                const int pos1 = s[c] + __popcll(m0) + prefix_popc(m1);
+                                if (DEFER) {
+                                    int* h = lhits + (wave * CPW + c) * K;
+                                    if (hit0 && pos0 < K) h[pos0] = c0 + k0;
+                                    if (hit1 && pos1 < K) h[pos1] = c0 + k1;
+                                } else {
+                                    const size_t o = ((size_t)i * M + j[c]) * K;
+                                    if (hit0 && pos0 < K) {
+                                        nnIndex[o + pos0] = c0 + k0;
+                                        nnDist[o + pos0] = sqrtf(sqrtf(d2.x));   // :47 then :54 — sqrt of the distance
+                                    }
+                                    if (hit1 && pos1 < K) {
+                                        nnIndex[o + pos1] = c0 + k1;
+                                        nnDist[o + pos1] = sqrtf(sqrtf(d2.y));
                                     }
                                 }
-                                s[c] += __popcll(mask);
+                                s[c] += __popcll(m0) + __popcll(m1);
                             }
                         }
                     }
