@@ -199,3 +199,17 @@ def test_shapenet_small_net_on_oracle_ops():
     assert tuple(params["store.params.logits/weights"].shape) == (2 * cfg.mlp, 3)
     for n, p in params.items():
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
+def test_bench_algorithmic_bytes_follow_the_survey_formulas():
+    """compulsory bytes per call = every distinct input / output element once (4 B each).  The roofline line of
+    bench.py is computed from these; checked here against the formulas written out by hand for the headline shapes."""
+    import bench
+    B, N, M, F, C, r, K = 16, 8192, 8192, 33, 128, 2, 64
+    fwd = 4 * (B * N * C + 2 * B * M * K + B * M + F * C * r + B * M * C * r)
+    assert bench.algorithmic_bytes("sph3d_depthwise_conv3d", (B, N, M, F, C, r, K)) == fwd == 268993536
+    nn = 4 * B * (3 * N + 3 * M + 2 * M * K + M)
+    assert bench.algorithmic_bytes("sph3d_build_sphere_neighbor", (B, N, M, K)) == nn
+    # both gradients in one call: read input, graph, counts, filter, grad_out; write grad_input and grad_filter
+    bwd = bench.algorithmic_bytes("sph3d_depthwise_conv3d_grad_t", (B, N, M, F, C, r))
+    assert bwd == 336136192
