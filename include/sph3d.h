@@ -202,6 +202,48 @@ int sph3d_farthest_point_sample(int b, int n, int m, const float* inp, int* out,
                                 void* workspace, size_t workspace_bytes,
                                 sph3d_stream_t stream);
 
+/* ---- LDS-tiled depthwise convolution (tile.hip, convtile.hip) ---------------------------------------
+ * Same results as sph3d_depthwise_conv3d / sph3d_depthwise_conv3d_grad_t (tf_ops/convolution/
+ * tf_conv3d_gpu.cu:7-101), for callers that keep a graph across calls: a per-graph TILE PLAN lets the kernels stage
+ * the union of the neighbour rows of 16 spatially consecutive points in LDS once and gather from LDS, with the
+ * edges of a point grouped by bin (rows of a bin are summed first, multiplied by the filter row once).
+ * Plan of one graph, all device arrays provided by the caller:
+ *   sph3d_spatial_order   order[B,N]: a permutation of each cloud in which consecutive points are close (Morton
+ *                         cells); any permutation is valid, a random one only loses the row reuse;
+ *   sph3d_rows_by_bin     forward graph as a binned CSR: bounds[B*M*(F+1)] (first entry of bin f of point m, then
+ *                         the end), key[B*M*K] neighbour ids sorted by bin inside each point's K-entry slab;
+ *                         needs K <= 64, F <= 63.  (The gradient uses the transposed graph of sph3d_graph_transpose.)
+ *   sph3d_tile_plan       targets T per cloud, NS source rows per cloud; shared_bounds = 0 for a rows_by_bin CSR
+ *                         (F+1 bounds per target), 1 for the sph3d_graph_transpose layout.  ucap = rows a tile may
+ *                         stage (multiple of 4, <= 252).  Outputs: tile_desc[B*ceil(T/16)*33], tile_rows (the
+ *                         unions), tile_row_scale (optional: 1/key_count[row] per listed row, for the gradient),
+ *                         pbounds[B*T*(F+1)] and slot_words: per (target, bin) group the LDS slots of its rows, one
+ *                         byte each, padded to whole words.  Sizes from sph3d_tile_plan_sizes (E = entries of the
+ *                         key array = B*M*K); pool_counter: 2 ints of scratch.
+ * variant = 100*V + W selects V channels per lane (2, 4) and W waves per workgroup (8, 16); 0 = default. */
+int sph3d_spatial_order(int B, int N, const float* xyz, int* order, sph3d_stream_t stream);
+int sph3d_rows_by_bin(int B, int M, int K, int F, const int* nn_index, const int* nn_count, const int* bin_index,
+                      int* bounds, int* key, sph3d_stream_t stream);
+int sph3d_tile_plan_sizes(int B, int T, int F, long long E, int* n_cands, size_t* desc_ints, size_t* rows_ints,
+                          size_t* pbounds_ints, size_t* slot_words);
+int sph3d_tile_plan(int B, int T, int NS, int F, int shared_bounds, int ucap,
+                    const int* order, const int* bounds, const int* key, const int* key_count,
+                    int* tile_desc, int* tile_rows, float* tile_row_scale, int* pbounds, int* slot_words,
+                    int* pool_counter, sph3d_stream_t stream);
+int sph3d_depthwise_conv3d_tiled(int B, int N, int M, int F, int C, int r, int ucap, int variant,
+                                 const int* order, const int* tile_desc, const int* tile_rows,
+                                 const int* pbounds, const int* slot_words, const int* nn_count,
+                                 const int* bounds, const int* key,
+                                 const float* input, const float* filter, float* output, sph3d_stream_t stream);
+size_t sph3d_depthwise_conv3d_grad_tiled_workspace(int F, int C, int r, int variant);
+int sph3d_depthwise_conv3d_grad_tiled(int B, int N, int M, int F, int C, int r, int ucap, int variant,
+                                      const int* order /* of the N source points */, const int* tile_desc,
+                                      const int* tile_rows, const float* tile_row_scale, const int* pbounds,
+                                      const int* slot_words, const int* offsets, const int* ent_key, const float* ent_scale,
+                                      const float* input, const float* filter, const float* grad_output,
+                                      float* grad_input, float* grad_filter,
+                                      void* workspace, size_t workspace_bytes, sph3d_stream_t stream);
+
 /* ---- pointwise 1x1 feature GEMM (fp32 MFMA) -----------------------------
  * replaces the tf.matmul inside separable_conv3d / pointwise_conv3d /
  * fully_connected (utils/sph3gcn_util.py:146-150, 204-206, 260) -> cuBLAS SGEMM

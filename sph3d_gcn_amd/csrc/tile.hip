@@ -1,0 +1,410 @@
+// tile.hip — tile plans for the LDS-tiled depthwise convolution (convtile.hip), gfx950.
+//
+// Why: the gather kernels of conv3d.hip fetch one feature row per edge through the CU's vector L1; the rows come from
+// L2 (the cloud is L2-resident) but every edge pays a full L1 miss.  Round-1 counters: L1 83 % occupied, HBM idle,
+// 10 % of the HBM roofline.  Spatially close output points share most of their neighbours (measured on the S3DIS-like
+// level-0 graph: 16 Morton-consecutive points reference 190 distinct rows for 770 edges), so a workgroup that stages
+// the UNION of a tile's rows in LDS once and gathers from LDS cuts the L1/L2 traffic 4x and turns every edge into one
+// ds_read.  That needs, per graph (not per convolution):
+//   1. sph3d_spatial_order   a processing order of the points in which consecutive points are close (Morton cells);
+//   2. sph3d_rows_by_bin     the forward graph as a binned CSR: per output point its edges sorted by bin (the
+//                            consumer sums the rows of one bin, then multiplies by the filter row ONCE per bin:
+//                            6 edges per (point, bin) group on S3DIS-like data -> 6x fewer filter reads and FMAs);
+//                            the gradient kernels already have this form (graph.hip: in-edges sorted by (source, bin));
+//   3. sph3d_tile_plan       tiles of kTileP consecutive targets: the tile's distinct source rows (ulist) and, per
+//                            edge, the slot of its row inside the tile.  A tile whose union exceeds the LDS capacity
+//                            is split (16 -> 8 -> ... -> 1 targets); a single target that still does not fit
+//                            (in-degree > capacity in the transposed graph) is marked "direct" and gathered from memory.
+// Everything here is integer work on the graph stream; results do not depend on the order (a tile only decides which
+// rows are staged together; the summation order of a target is fixed by its CSR).
+#include "common.hpp"
+
+namespace sph3d {
+
+// ---------------------------------------------------------------------------------------------------------------
+// 1. spatial order: counting sort of a cloud's points by the Morton code of their cell in a 2^bpa-per-axis grid over
+//    the bounding box (cells isotropic, sized by the longest axis).  One 1024-thread workgroup per cloud, histogram
+//    in LDS (<= 32768 buckets).  Order inside a cell = arrival order of an LDS atomic (irrelevant for results).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned spread3(unsigned v)      // 10 bits -> every third bit
+{
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__global__ __launch_bounds__(1024) void spatial_order_kernel(int N, int bpa, const float* __restrict__ xyz,
+                                                              int* __restrict__ order)
+{
+    extern __shared__ int hist[];                  // [1 << 3*bpa]
+    __shared__ float red[6][16];
+    __shared__ int wsum[16];
+    const int b = (int)blockIdx.x;
+    const int tid = (int)threadIdx.x;
+    const int NB = 1 << (3 * bpa);
+    const float* p = xyz + (size_t)b * N * 3;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int n = tid; n < N; n += 1024)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float v = p[n * 3 + a];
+            lo[a] = fminf(lo[a], v);
+            hi[a] = fmaxf(hi[a], v);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], o));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o));
+        }
+    if ((tid & 63) == 0)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            red[a][tid >> 6] = lo[a];
+            red[3 + a][tid >> 6] = hi[a];
+        }
+    for (int i = tid; i < NB; i += 1024) hist[i] = 0;
+    __syncthreads();
+    float ext = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float l = red[a][0], h = red[3 + a][0];
+        for (int w = 1; w < 16; w++) {
+            l = fminf(l, red[a][w]);
+            h = fmaxf(h, red[3 + a][w]);
+        }
+        lo[a] = l;
+        ext = fmaxf(ext, h - l);
+    }
+    const int G = 1 << bpa;
+    const float inv = ext > 0.f ? (float)G / ext : 0.f;
+    auto key_of = [&](int n) {
+        unsigned k = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            int q = (int)((p[n * 3 + a] - lo[a]) * inv);
+            q = q < 0 ? 0 : (q > G - 1 ? G - 1 : q);
+            k |= spread3((unsigned)q) << a;
+        }
+        return (int)k;
+    };
+    for (int n = tid; n < N; n += 1024) atomicAdd(&hist[key_of(n)], 1);
+    __syncthreads();
+    // exclusive scan of the histogram: each thread owns NB/1024 consecutive buckets (NB >= 1024 by construction)
+    const int per = NB >> 10;
+    int s = 0;
+    for (int j = 0; j < per; j++) s += hist[tid * per + j];
+    int incl = s;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if ((tid & 63) >= o) incl += t;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (tid >> 6); w++) base += wsum[w];
+    int run = base + incl - s;
+    for (int j = 0; j < per; j++) {
+        const int c = hist[tid * per + j];
+        hist[tid * per + j] = run;
+        run += c;
+    }
+    __syncthreads();
+    for (int n = tid; n < N; n += 1024) order[(size_t)b * N + atomicAdd(&hist[key_of(n)], 1)] = n;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 2. forward graph as a binned CSR: one wave per output point; lane k holds slot k (K <= 64), a ballot per bin gives
+//    the segment sizes and every edge's position.  Layout: bounds[(b*M+m)*(F+1) + f] = first entry of bin f,
+//    bounds[..+F] = end; entries of point (b,m) live in [ (b*M+m)*K, +cnt ); key[] = neighbour (source row) id.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rows_by_bin_kernel(int rows_total, int K, int F, const int* __restrict__ nnIndex,
+                                                          const int* __restrict__ nnCount, const int* __restrict__ binIndex,
+                                                          int* __restrict__ bounds, int* __restrict__ key)
+{
+    const int row = (int)blockIdx.x * 4 + uniform((int)threadIdx.x >> 6);
+    if (row >= rows_total) return;
+    const int lane = lane_id();
+    int cnt = uniform(nnCount[row]);
+    cnt = cnt < 0 ? 0 : (cnt > K ? K : cnt);
+    const bool valid = lane < cnt;
+    const size_t base = (size_t)row * K;
+    const int n = valid ? nnIndex[base + lane] : 0;
+    int f = valid ? binIndex[base + lane] : -1;
+    if (valid) f = f < 0 ? 0 : (f >= F ? F - 1 : f);
+    int run = 0, mybound = 0, dest = 0;
+    for (int b = 0; b < F; b++) {
+        const unsigned long long mask = __ballot(f == b);
+        if (lane == b) mybound = run;
+        if (f == b) dest = run + prefix_popc(mask);
+        run += __popcll(mask);
+    }
+    if (lane == F) mybound = run;
+    if (lane <= F) bounds[(size_t)row * (F + 1) + lane] = (int)base + mybound;
+    if (valid) key[base + dest] = n;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3. tile plan.  Candidate tile = kTileP consecutive positions of `order` (identity when null).  One 256-thread
+//    workgroup per candidate: bitmap of the referenced source rows in LDS -> union size; split in halves until every
+//    sub-tile fits `ucap` rows; then ranks by prefix popcounts -> ulist (and 1/count per listed row for the gradient
+//    kernel, which stages pre-scaled rows) and slot[e] for every edge of the tile's targets.
+//    desc[cand][0] = targets per sub-tile g; desc[cand][1+2s] = rows of sub-tile s (-1: direct), [2+2s] = first ulist entry.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool SHARED_BOUNDS>
+__device__ __forceinline__ void target_range(const int* __restrict__ bounds, int b, int T, int F, int t, int& e0, int& e1)
+{
+    if (SHARED_BOUNDS) {          // graph.hip layout: offsets[b*(T*F+1) + t*F + f], end of bin F-1 = next target's bin 0
+        const int* o = bounds + (size_t)b * ((size_t)T * F + 1) + (size_t)t * F;
+        e0 = o[0];
+        e1 = o[F];
+    } else {                       // rows_by_bin layout: F+1 bounds per target
+        const int* o = bounds + ((size_t)b * T + t) * (F + 1);
+        e0 = o[0];
+        e1 = o[F];
+    }
+}
+
+// marks the source rows of targets [p0, p1) in the LDS bitmap, fills the exclusive prefix popcounts and returns the union
+// size (workgroup-uniform); 256 threads
+__device__ __forceinline__ int plan_build(unsigned* lbits, unsigned* lpre, int* scan, int W, const int* __restrict__ key,
+                                          const int* te0, const int* te1, int p0, int p1)
+{
+    const int tid = (int)threadIdx.x;
+    for (int i = tid; i < W; i += 256) lbits[i] = 0u;
+    __syncthreads();
+    for (int p = p0; p < p1; p++)
+        for (int e = te0[p] + tid; e < te1[p]; e += 256) {
+            const int n = key[e];
+            atomicOr(&lbits[n >> 5], 1u << (n & 31));
+        }
+    __syncthreads();
+    const int per = (W + 255) >> 8;
+    int s = 0;
+    for (int j = 0; j < per; j++) {
+        const int i = tid * per + j;
+        if (i < W) s += __popc(lbits[i]);
+    }
+    scan[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int a = tid >= o ? scan[tid - o] : 0;
+        __syncthreads();
+        scan[tid] += a;
+        __syncthreads();
+    }
+    int run = scan[tid] - s;
+    for (int j = 0; j < per; j++) {
+        const int i = tid * per + j;
+        if (i < W) {
+            lpre[i] = (unsigned)run;
+            run += __popc(lbits[i]);
+        }
+    }
+    const int total = scan[255];
+    __syncthreads();
+    return total;
+}
+
+template <bool SHARED_BOUNDS>
+__global__ __launch_bounds__(256) void tile_plan_kernel(int B, int T, int NS, int F, int cands, int ucap,
+                                                        const int* __restrict__ order, const int* __restrict__ bounds,
+                                                        const int* __restrict__ key, const int* __restrict__ keyCount,
+                                                        int* __restrict__ desc, int* __restrict__ ulist,
+                                                        float* __restrict__ uscale, int* __restrict__ pbounds,
+                                                        unsigned char* __restrict__ slot8, int* __restrict__ pool)
+{
+    extern __shared__ unsigned lbits[];           // [W] bitmap, then [W] exclusive prefix popcounts
+    __shared__ int scan[256];
+    __shared__ int tgt[kTileP], te0[kTileP], te1[kTileP], subU[kTileP], subOff[kTileP];
+    __shared__ int sh_alloc;
+    const int W = (NS + 31) >> 5;
+    unsigned* lpre = lbits + W;
+    const int tid = (int)threadIdx.x;
+    const int b = (int)blockIdx.x / cands, c = (int)blockIdx.x % cands;
+    const int pos0 = c * kTileP;
+    const int npts = (T - pos0) < kTileP ? (T - pos0) : kTileP;
+    if (tid < kTileP) {
+        int e0 = 0, e1 = 0, t = 0;
+        if (tid < npts) {
+            t = order ? order[(size_t)b * T + pos0 + tid] : pos0 + tid;
+            target_range<SHARED_BOUNDS>(bounds, b, T, F, t, e0, e1);
+        }
+        tgt[tid] = t;
+        te0[tid] = e0;
+        te1[tid] = e1;
+    }
+    __syncthreads();
+
+    // largest sub-tile size whose unions all fit
+    int g = kTileP;
+    for (;;) {
+        bool ok = true;
+        for (int s = 0; s * g < npts; s++) {
+            const int p1 = ((s + 1) * g) < npts ? ((s + 1) * g) : npts;
+            const int U = plan_build(lbits, lpre, scan, W, key, te0, te1, s * g, p1);
+            if (tid == 0) subU[s] = U;
+            if (U > ucap) {
+                ok = false;
+                if (g > 1) break;
+            }
+        }
+        if (ok || g == 1) break;
+        g >>= 1;
+    }
+    __syncthreads();
+    const int nsub = (npts + g - 1) / g;
+    if (tid == 0) {
+        int tot = 0;
+        for (int s = 0; s < nsub; s++) {
+            const int U = subU[s];
+            subOff[s] = tot;
+            if (U <= ucap) tot += U;
+        }
+        sh_alloc = atomicAdd(&pool[0], tot);
+    }
+    __syncthreads();
+    int* d = desc + ((size_t)b * cands + c) * kDescInts;
+    if (tid == 0) d[0] = g;
+    if (tid < kTileP) {
+        const bool have = tid < nsub;
+        const bool direct = have && subU[tid] > ucap;
+        d[1 + 2 * tid] = have ? (direct ? -1 : subU[tid]) : 0;
+        d[2 + 2 * tid] = have ? sh_alloc + subOff[tid] : 0;
+    }
+    const int wave = uniform(tid >> 6);
+    const int lane = lane_id();
+    for (int s = 0; s < nsub; s++) {
+        if (subU[s] > ucap) continue;               // direct sub-tile: the consumer gathers from memory by key
+        const int p0 = s * g, p1 = ((s + 1) * g) < npts ? ((s + 1) * g) : npts;
+        if (nsub > 1 || g < kTileP) plan_build(lbits, lpre, scan, W, key, te0, te1, p0, p1);   // else: still in LDS from the search
+        const int uoff = sh_alloc + subOff[s];
+        for (int i = tid; i < W; i += 256) {
+            unsigned bits = lbits[i];
+            int r = (int)lpre[i];
+            while (bits) {
+                const int bit = __builtin_ctz(bits);
+                bits &= bits - 1;
+                const int n = (i << 5) + bit;
+                ulist[uoff + r] = n;
+                if (uscale) uscale[uoff + r] = 1.0f / (float)keyCount[(size_t)b * NS + n];
+                r++;
+            }
+        }
+        // slot bytes: one wave per target; each (target, bin) group padded to a multiple of 4 (pad = the zero row `ucap`)
+        for (int p = p0 + wave; p < p1; p += 4) {
+            const int t = tgt[p];
+            const int* __restrict__ o = SHARED_BOUNDS ? bounds + (size_t)b * ((size_t)T * F + 1) + (size_t)t * F
+                                                      : bounds + ((size_t)b * T + t) * (F + 1);
+            const int ov = o[lane <= F ? lane : F];
+            const int nx = __shfl_down(ov, 1);
+            const int len = lane < F ? nx - ov : 0;
+            const int pad = (len + 3) >> 2;
+            int incl = pad;
+            for (int q = 1; q < 64; q <<= 1) {
+                const int u = __shfl_up(incl, q);
+                if (lane >= q) incl += u;
+            }
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&pool[1], total);
+            base = uniform(base);
+            const int dstart = base + incl - pad;
+            if (lane <= F) pbounds[((size_t)b * T + t) * (F + 1) + lane] = dstart;
+            unsigned long long mask = __ballot(len > 0);
+            while (mask) {
+                const int f = (int)__builtin_ctzll(mask);
+                mask &= mask - 1;
+                const int e0 = __builtin_amdgcn_readlane(ov, f);
+                const int L = __builtin_amdgcn_readlane(len, f);
+                const int d0 = __builtin_amdgcn_readlane(dstart, f);
+                const int P4 = ((L + 3) >> 2) << 2;
+                for (int j = lane; j < P4; j += 64) {
+                    int v = ucap;
+                    if (j < L) {
+                        const int n = key[e0 + j];
+                        v = (int)lpre[n >> 5] + __popc(lbits[n >> 5] & ((1u << (n & 31)) - 1u));
+                    }
+                    slot8[(size_t)4 * d0 + j] = (unsigned char)v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace sph3d
+
+using namespace sph3d;
+
+extern "C" int sph3d_spatial_order(int B, int N, const float* xyz, int* order, sph3d_stream_t stream)
+{
+    SPH3D_REQUIRE(B >= 0 && N > 0, "spatial_order: bad dims B=%d N=%d", B, N);
+    if (B == 0) return SPH3D_OK;
+    int bpa = 4;                                   // buckets ~ 4 N, between 2^12 and 2^15
+    while (bpa < 5 && (1 << (3 * bpa)) < 4 * N) bpa++;
+    const size_t lds = sizeof(int) * ((size_t)1 << (3 * bpa));
+    int rc = SPH3D_OK;
+    if (lds > 64 * 1024) {
+        rc = check_hip(hipFuncSetAttribute((const void*)spatial_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                       "spatial_order: hipFuncSetAttribute");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(spatial_order_kernel, dim3(B), dim3(1024), lds, as_stream(stream), N, bpa, xyz, order);
+    return check_launch("sph3d_spatial_order");
+}
+
+extern "C" int sph3d_rows_by_bin(int B, int M, int K, int F, const int* nn_index, const int* nn_count, const int* bin_index,
+                                 int* bounds, int* key, sph3d_stream_t stream)
+{
+    SPH3D_REQUIRE(B >= 0 && M >= 0 && K > 0 && F > 0, "rows_by_bin: bad dims B=%d M=%d K=%d F=%d", B, M, K, F);
+    SPH3D_REQUIRE(K <= 64 && F <= 63, "rows_by_bin: needs K <= 64 and F <= 63 (got K=%d F=%d)", K, F);
+    SPH3D_REQUIRE((long long)B * M * K < (1LL << 31), "rows_by_bin: B*M*K overflows int32");
+    const int rows = B * M;
+    if (rows == 0) return SPH3D_OK;
+    hipLaunchKernelGGL(rows_by_bin_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), rows, K, F, nn_index, nn_count,
+                       bin_index, bounds, key);
+    return check_launch("sph3d_rows_by_bin");
+}
+
+extern "C" int sph3d_tile_plan_sizes(int B, int T, int F, long long E, int* n_cands, size_t* desc_ints, size_t* rows_ints,
+                                     size_t* pbounds_ints, size_t* slot_words)
+{
+    const int cands = (T + kTileP - 1) / kTileP;
+    if (n_cands) *n_cands = cands;
+    if (desc_ints) *desc_ints = (size_t)B * cands * kDescInts;
+    if (rows_ints) *rows_ints = (size_t)(E > 0 ? E : 1) + 64;          // sum of the unions <= number of edges
+    if (pbounds_ints) *pbounds_ints = (size_t)B * T * (F + 1);
+    // every non-empty group wastes < 4 bytes and there are <= min(E, T*F) groups: words <= (E + 3 min(E, B*T*F)) / 4 <= E
+    if (slot_words) *slot_words = (size_t)(E > 0 ? E : 1) + 64;
+    return SPH3D_OK;
+}
+
+extern "C" int sph3d_tile_plan(int B, int T, int NS, int F, int shared_bounds, int ucap,
+                               const int* order, const int* bounds, const int* key, const int* key_count,
+                               int* tile_desc, int* tile_rows, float* tile_row_scale, int* pbounds, int* slot_words,
+                               int* pool_counter, sph3d_stream_t stream)
+{
+    SPH3D_REQUIRE(B >= 0 && T > 0 && NS > 0 && F > 0 && F <= 63, "tile_plan: bad dims B=%d T=%d NS=%d F=%d", B, T, NS, F);
+    SPH3D_REQUIRE(ucap >= 4 && ucap <= 252 && ucap % 4 == 0, "tile_plan: ucap=%d must be a multiple of 4 in [4, 252]", ucap);
+    SPH3D_REQUIRE(tile_row_scale == nullptr || key_count != nullptr, "tile_plan: tile_row_scale needs key_count");
+    if (B == 0) return SPH3D_OK;
+    const int cands = (T + kTileP - 1) / kTileP;
+    const size_t lds = sizeof(unsigned) * 2 * (size_t)((NS + 31) >> 5);
+    SPH3D_REQUIRE(lds <= 150 * 1024, "tile_plan: %d source rows do not fit the LDS bitmap", NS);
+    hipStream_t st = as_stream(stream);
+    int rc = check_hip(hipMemsetAsync(pool_counter, 0, 2 * sizeof(int), st), "tile_plan: memset");
+    if (rc) return rc;
+    auto kern = shared_bounds ? tile_plan_kernel<true> : tile_plan_kernel<false>;
+    if (lds > 60 * 1024) {
+        rc = check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                       "tile_plan: hipFuncSetAttribute");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(kern, dim3(B * cands), dim3(256), lds, st, B, T, NS, F, cands, ucap, order, bounds, key, key_count, tile_desc,
+                       tile_rows, tile_row_scale, pbounds, (unsigned char*)slot_words, pool_counter);
+    return check_launch("sph3d_tile_plan");
+}

@@ -4,7 +4,7 @@ PyTorch custom op ``sph3d::spherical_kernel`` (no gradient, :34).
 """
 import torch
 
-from . import _lib
+from . import _lib, _plan
 
 
 def _spherical_kernel_impl(database: torch.Tensor, query: torch.Tensor, nn_index: torch.Tensor,
@@ -27,6 +27,8 @@ def _spherical_kernel_impl(database: torch.Tensor, query: torch.Tensor, nn_index
     _lib.check(_lib.lib().sph3d_spherical_kernel(
         B, N, M, K, n_azim, p_elev, q_radi, radius, _lib.ptr(database), _lib.ptr(query),
         _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(nn_dist), _lib.ptr(filt_index), _lib.stream_ptr()))
+    # the convolutions that will use these bins can tile their work spatially: remember which coordinates they came from
+    _plan.register_geometry(filt_index, database, query)
     return filt_index
 
 
