@@ -31,7 +31,6 @@ import torch
 import torch.distributed as dist
 
 from sph3d_gcn_amd import _lib
-from sph3d_gcn_amd import tf_gemm
 from sph3d_gcn_amd.harness import dist as hdist
 from sph3d_gcn_amd.harness import s3dis_net, synth
 
@@ -195,7 +194,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hipgraph", action="store_true", help="capture fwd+bwd into a HIP graph and replay it (experimental)")
-    ap.add_argument("--gemm", default=os.environ.get("SPH3D_GEMM", tf_gemm.get_backend()))
     args = ap.parse_args()
 
     rank, world, local_rank = hdist.init_from_env()
@@ -204,7 +202,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     _lib.lib()
-    tf_gemm.set_backend(args.gemm)
 
     pts, label, inner = make_batch(rank, dev)
     torch.cuda.synchronize()
@@ -358,7 +355,7 @@ def main():
                                    "%d blocks/GPU, graph build + fwd + bwd + Adam" % BLOCKS_PER_GPU,
                        "global_batch": world * BLOCKS_PER_GPU, "points_per_block": NUM_POINT,
                        "parallelism": "dp%d (one cloud shard per GPU, one flat RCCL grad all-reduce)" % world,
-                       "params": nparams, "gemm_backend": tf_gemm.get_backend(), "launch_mode": mode},
+                       "params": nparams, "launch_mode": mode},
             "loss": round(float(loss), 5),
             "sph3d_kernels_ms_per_step": round(sph3d_ms, 3),
             "roofline": roofline,

@@ -203,8 +203,8 @@ int sph3d_farthest_point_sample(int b, int n, int m, const float* inp, int* out,
                                 sph3d_stream_t stream);
 
 /* ---- LDS-tiled depthwise convolution (tile.hip, convtile.hip) ---------------------------------------
- * Same results as sph3d_depthwise_conv3d / sph3d_depthwise_conv3d_grad_t (tf_ops/convolution/
- * tf_conv3d_gpu.cu:7-101), for callers that keep a graph across calls: a per-graph TILE PLAN lets the kernels stage
+ * Same results as sph3d_depthwise_conv3d (tf_ops/convolution/tf_conv3d_gpu.cu:7-29), for callers that keep a graph
+ * across calls: a per-graph TILE PLAN lets the kernels stage
  * the union of the neighbour rows of 16 spatially consecutive points in LDS once and gather from LDS, with the
  * edges of a point grouped by bin (rows of a bin are summed first, multiplied by the filter row once).
  * Plan of one graph, all device arrays provided by the caller:
@@ -212,37 +212,33 @@ int sph3d_farthest_point_sample(int b, int n, int m, const float* inp, int* out,
  *                         cells); any permutation is valid, a random one only loses the row reuse;
  *   sph3d_rows_by_bin     forward graph as a binned CSR: bounds[B*M*(F+1)] (first entry of bin f of point m, then
  *                         the end), key[B*M*K] neighbour ids sorted by bin inside each point's K-entry slab;
- *                         needs K <= 64, F <= 63.  (The gradient uses the transposed graph of sph3d_graph_transpose.)
- *   sph3d_tile_plan       targets T per cloud, NS source rows per cloud; shared_bounds = 0 for a rows_by_bin CSR
- *                         (F+1 bounds per target), 1 for the sph3d_graph_transpose layout.  ucap = rows a tile may
- *                         stage (multiple of 4, <= 252).  Outputs: tile_desc[B*ceil(T/16)*33], tile_rows (the
- *                         unions), tile_row_scale (optional: 1/key_count[row] per listed row, for the gradient),
- *                         pbounds[B*T*(F+1)] and slot_words: per (target, bin) group the LDS slots of its rows, one
- *                         byte each, padded to whole words.  Sizes from sph3d_tile_plan_sizes (E = entries of the
- *                         key array = B*M*K); pool_counter: 2 ints of scratch.
- * variant = 100*V + W selects V channels per lane (2, 4) and W waves per workgroup (8, 16); 0 = default. */
+ *                         needs K <= 64, F <= 63;
+ *   sph3d_tile_plan       T targets and NS source rows per cloud, bounds / key from sph3d_rows_by_bin.  ucap = rows a
+ *                         tile may stage (multiple of 4, <= 252; >= K).  F <= 62.  Outputs, all at addresses
+ *                         computed from the tile index cand = b*ceil(T/16) + c, so that a kernel can fetch a tile's
+ *                         data two tiles ahead: tile_hdr[cand*2] = {targets, rows} of the tile's first sub-tile;
+ *                         tile_rows[cand*ucap + i] its row list; tile_targets[cand*16 + i] the tile's targets;
+ *                         tile_pb[(cand*16+i)*(F+2)]: first slot word of each bin of target i, end, edge count;
+ *                         slot_words[(cand*16+i)*64 + j]: per (target, bin) group the LDS slots of its rows, one byte
+ *                         each, padded to whole words.  Further sub-tiles of a tile whose union did not fit go to
+ *                         extra_steps[b] (8 ints each; counters[1+b] of them), their row lists behind the fixed part
+ *                         of tile_rows.  Sizes from sph3d_tile_plan_sizes (E = B*M*K).
+ * The tiled kernel covers C >= 128 (128-channel row slices), r in {1,2}, F*128*r*4 + (ucap+2)*512 B <= 160 KiB. */
 int sph3d_spatial_order(int B, int N, const float* xyz, int* order, sph3d_stream_t stream);
 int sph3d_rows_by_bin(int B, int M, int K, int F, const int* nn_index, const int* nn_count, const int* bin_index,
                       int* bounds, int* key, sph3d_stream_t stream);
-int sph3d_tile_plan_sizes(int B, int T, int F, long long E, int* n_cands, size_t* desc_ints, size_t* rows_ints,
-                          size_t* pbounds_ints, size_t* slot_words);
-int sph3d_tile_plan(int B, int T, int NS, int F, int shared_bounds, int ucap,
-                    const int* order, const int* bounds, const int* key, const int* key_count,
-                    int* tile_desc, int* tile_rows, float* tile_row_scale, int* pbounds, int* slot_words,
-                    int* pool_counter, sph3d_stream_t stream);
-int sph3d_depthwise_conv3d_tiled(int B, int N, int M, int F, int C, int r, int ucap, int variant,
-                                 const int* order, const int* tile_desc, const int* tile_rows,
-                                 const int* pbounds, const int* slot_words, const int* nn_count,
-                                 const int* bounds, const int* key,
+int sph3d_tile_plan_sizes(int B, int T, int F, int ucap, long long E, int* n_cands, size_t* hdr_ints, size_t* tgt_ints,
+                          size_t* rows_ints, size_t* pb_ints, size_t* slot_words, size_t* xstep_ints, size_t* counter_ints);
+int sph3d_tile_plan(int B, int T, int NS, int F, int ucap,
+                    const int* order, const int* bounds, const int* key,
+                    int* tile_hdr, int* tile_targets, int* tile_rows, int* tile_pb,
+                    int* slot_words, int* extra_steps, int* counters, sph3d_stream_t stream);
+int sph3d_depthwise_conv3d_tiled_supported(int F, int C, int r, int K, int ucap);   /* 1 if the tiled kernel applies */
+int sph3d_depthwise_conv3d_tiled(int B, int N, int M, int F, int C, int r, int ucap,
+                                 const int* tile_hdr, const int* tile_targets, const int* tile_rows,
+                                 const int* tile_pb, const int* slot_words, const int* extra_steps,
+                                 const int* counters,
                                  const float* input, const float* filter, float* output, sph3d_stream_t stream);
-size_t sph3d_depthwise_conv3d_grad_tiled_workspace(int F, int C, int r, int variant);
-int sph3d_depthwise_conv3d_grad_tiled(int B, int N, int M, int F, int C, int r, int ucap, int variant,
-                                      const int* order /* of the N source points */, const int* tile_desc,
-                                      const int* tile_rows, const float* tile_row_scale, const int* pbounds,
-                                      const int* slot_words, const int* offsets, const int* ent_key, const float* ent_scale,
-                                      const float* input, const float* filter, const float* grad_output,
-                                      float* grad_input, float* grad_filter,
-                                      void* workspace, size_t workspace_bytes, sph3d_stream_t stream);
 
 /* ---- pointwise 1x1 feature GEMM (fp32 MFMA) -----------------------------
  * replaces the tf.matmul inside separable_conv3d / pointwise_conv3d /

@@ -119,6 +119,10 @@ class tf_unpool3d:
     weighted_interpolate = staticmethod(lambda *a: _Weighted.apply(*a))
 
 
+class tf_gemm:
+    matmul = staticmethod(torch.matmul)
+
+
 @contextlib.contextmanager
 def patched_util():
     """Temporarily point sph3d_gcn_amd.sph3gcn_util at the oracle ops (CPU tensors).  bench.py's cpu_baseline
@@ -126,12 +130,12 @@ def patched_util():
     from sph3d_gcn_amd import sph3gcn_util as u
     saved = dict(tf_conv3d=u.tf_conv3d, tf_pool3d=u.tf_pool3d, tf_unpool3d=u.tf_unpool3d, neighbor_fn=u.neighbor_fn,
                  farthest_point_sample=u.farthest_point_sample, spherical_kernel=u.spherical_kernel,
-                 gemm=u.tf_gemm.get_backend())
+                 tf_gemm=u.tf_gemm)
     u.tf_conv3d, u.tf_pool3d, u.tf_unpool3d = tf_conv3d, tf_pool3d, tf_unpool3d
     u.neighbor_fn = build_sphere_neighbor
     u.farthest_point_sample = farthest_point_sample
     u.spherical_kernel = spherical_kernel
-    u.tf_gemm.set_backend("blas")          # CPU GEMMs through torch.matmul (MKL/oneDNN): baseline not handicapped
+    u.tf_gemm = tf_gemm                    # CPU GEMMs through torch.matmul (MKL/oneDNN): baseline not handicapped
     try:
         yield u
     finally:
@@ -139,4 +143,4 @@ def patched_util():
         u.neighbor_fn = saved["neighbor_fn"]
         u.farthest_point_sample = saved["farthest_point_sample"]
         u.spherical_kernel = saved["spherical_kernel"]
-        u.tf_gemm.set_backend(saved["gemm"])
+        u.tf_gemm = saved["tf_gemm"]

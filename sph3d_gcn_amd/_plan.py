@@ -1,12 +1,15 @@
 """Per-graph tile plans of the LDS-tiled depthwise convolution (include/sph3d.h: sph3d_tile_plan).
 
-A plan belongs to a neighbour graph, not to a convolution: the two separable convolutions of a level, their
-gradients and every later step that reuses the tensors share it.  It needs the coordinates of the graph's points
-(to put spatially close points in one tile); the convolution op itself never sees coordinates
-(tf_ops/convolution/tf_conv3d.py:10-21), so ``tf_buildkernel.spherical_kernel`` — the op that produced the bin
-indices from the coordinates — registers them here, keyed by the identity of its output tensor.  A convolution
-called with a ``bin_index`` nobody registered (or a shape the tiled kernels do not cover) runs the gather kernels of
-conv3d.hip; results are the same either way.
+A plan belongs to a neighbour graph, not to a convolution: every convolution that reuses the graph's tensors shares
+it.  It needs the coordinates of the graph's points (to put spatially close points in one tile); the convolution op
+itself never sees coordinates (tf_ops/convolution/tf_conv3d.py:10-21), so ``tf_buildkernel.spherical_kernel`` — the op
+that produced the bin indices from the coordinates — registers them here, keyed by the identity of its output tensor.
+
+Measured trade-off (round 2, MI355X, B = 16 x 8192 points): the tiled forward kernel runs a C = 128 layer in 0.207 ms
+against 0.275 ms for the gather kernel, but a plan costs 0.32 ms per level-0 graph.  A training step builds new graphs
+every step and uses each for two forward convolutions, so the default mode is ``"gather"``; ``set_mode("tiled")`` is for
+callers that keep a graph (inference on a fixed cloud, many steps on one batch) and for the tests / tools.  Results are
+the same either way up to fp32 summation order.
 
 Entries hold strong references to the tensors they were built from (so a data_ptr cannot be recycled for another
 graph while its entry lives) and an event for consumers on other streams, like ``_tgraph``.
@@ -16,25 +19,24 @@ import ctypes
 
 import torch
 
-from . import _lib, _tgraph
+from . import _lib
 
-UCAP = 236            # rows a tile stages: (UCAP + 4) * 256 B of rows + a 17-KB filter slice fit twice in a CU's 160-KB LDS
+UCAP = 236            # rows a tile stages: (UCAP + 2) * 512 B of rows + the 33-KB filter of 33 bins x 256 outputs fit 160 KB of LDS
 MIN_POINTS = 64       # below this a level is a handful of tiles: the gather kernels are used
-_MAX_ENTRIES = 24
+_MAX_ENTRIES = 16
 
-_mode = "auto"        # "auto" | "direct" (never tile) — a switch for tests and tools/, not a second backend
-_variant = 0
-
-
-def set_mode(mode, variant=0):
-    global _mode, _variant
-    if mode not in ("auto", "direct"):
-        raise ValueError("mode must be 'auto' or 'direct'")
-    _mode, _variant = mode, int(variant)
+_mode = "gather"      # "gather" | "tiled": which forward kernel a convolution with a registered graph geometry uses
 
 
-def variant():
-    return _variant
+def set_mode(mode):
+    global _mode
+    if mode not in ("gather", "tiled"):
+        raise ValueError("mode must be 'gather' or 'tiled'")
+    _mode = mode
+
+
+def get_mode():
+    return _mode
 
 
 def _ident(t):
@@ -44,11 +46,10 @@ def _ident(t):
 _geom = collections.OrderedDict()      # ident(bin_index) -> (database_xyz, query_xyz, bin_index)
 _orders = collections.OrderedDict()    # ident(xyz) -> entry
 _fwd = collections.OrderedDict()
-_bwd = collections.OrderedDict()
 
 
 def clear():
-    for d in (_geom, _orders, _fwd, _bwd):
+    for d in (_geom, _orders, _fwd):
         d.clear()
 
 
@@ -95,36 +96,16 @@ def spatial_order(xyz):
     return _entry(_orders, (_ident(xyz), tuple(xyz.shape)), build, (xyz,))[0]
 
 
-def _sizes(B, T, F, E):
-    n_c = ctypes.c_int()
-    d, r, p, w = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
-    _lib.check(_lib.lib().sph3d_tile_plan_sizes(B, T, F, ctypes.c_longlong(E), ctypes.byref(n_c), ctypes.byref(d),
-                                                ctypes.byref(r), ctypes.byref(p), ctypes.byref(w)))
-    return d.value, r.value, p.value, w.value
-
-
-def _tile_plan(B, T, NS, F, E, shared, order, bounds, key, key_count, dev, ucap):
-    di, ri, pi, wi = _sizes(B, T, F, E)
-    i32 = dict(dtype=torch.int32, device=dev)
-    desc = torch.empty((di,), **i32)
-    rows = torch.empty((ri,), **i32)
-    scale = torch.empty((ri,), dtype=torch.float32, device=dev) if key_count is not None else None
-    pbounds = torch.empty((pi,), **i32)
-    slotw = torch.empty((wi,), **i32)
-    pool = torch.empty((2,), **i32)
-    _lib.check(_lib.lib().sph3d_tile_plan(B, T, NS, F, 1 if shared else 0, ucap, _lib.ptr(order), _lib.ptr(bounds),
-                                          _lib.ptr(key), _lib.ptr(key_count), _lib.ptr(desc), _lib.ptr(rows),
-                                          _lib.ptr(scale), _lib.ptr(pbounds), _lib.ptr(slotw), _lib.ptr(pool),
-                                          _lib.stream_ptr()))
-    return desc, rows, scale, pbounds, slotw
-
-
-def eligible(N, M, K, F, C, r):
-    return (_mode == "auto" and C % 4 == 0 and r in (1, 2) and F <= 63 and K <= 64 and min(N, M) >= MIN_POINTS)
+def applies(N, M, K, F, C, r, ucap=None):
+    """does the tiled forward kernel cover this layer (and is the mode on)?"""
+    ucap = UCAP if ucap is None else int(ucap)
+    return (_mode == "tiled" and K <= 64 and min(N, M) >= MIN_POINTS
+            and bool(_lib.lib().sph3d_depthwise_conv3d_tiled_supported(F, C, r, K, ucap)))
 
 
 def forward_plan(nn_index, nn_count, bin_index, F, ucap=None):
-    """-> (order, desc, rows, pbounds, slotw, bounds, key, ucap) or None when the graph's coordinates are unknown"""
+    """-> (hdr, targets, rows, pb, slotw, xsteps, counters, bounds, key, ucap) (see include/sph3d.h: sph3d_tile_plan), or
+    None when nobody registered the coordinates of this graph"""
     g = _geom.get(_ident(bin_index))
     if g is None:
         return None
@@ -136,37 +117,22 @@ def forward_plan(nn_index, nn_count, bin_index, F, ucap=None):
 
     def build():
         dev = nn_index.device
+        l = _lib.lib()
         order = spatial_order(query)
         bounds = torch.empty((B * M * (F + 1),), dtype=torch.int32, device=dev)
         key = torch.empty((B * M * K + 64,), dtype=torch.int32, device=dev)
-        _lib.check(_lib.lib().sph3d_rows_by_bin(B, M, K, F, _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(bin_index),
-                                                _lib.ptr(bounds), _lib.ptr(key), _lib.stream_ptr()))
+        _lib.check(l.sph3d_rows_by_bin(B, M, K, F, _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(bin_index),
+                                       _lib.ptr(bounds), _lib.ptr(key), _lib.stream_ptr()))
         N = g[0].shape[1]
-        desc, rows, _s, pbounds, slotw = _tile_plan(B, M, N, F, B * M * K, False, order, bounds, key, None, dev, ucap)
-        return (order, desc, rows, pbounds, slotw, bounds, key, ucap)
+        n_c = ctypes.c_int()
+        sz = [ctypes.c_size_t() for _ in range(7)]
+        _lib.check(l.sph3d_tile_plan_sizes(B, M, F, ucap, ctypes.c_longlong(B * M * K), ctypes.byref(n_c),
+                                           *[ctypes.byref(x) for x in sz]))
+        hdr, tgt, rows, pb, slotw, xsteps, counters = (torch.empty((x.value,), dtype=torch.int32, device=dev) for x in sz)
+        _lib.check(l.sph3d_tile_plan(B, M, N, F, ucap, _lib.ptr(order), _lib.ptr(bounds), _lib.ptr(key), _lib.ptr(hdr),
+                                     _lib.ptr(tgt), _lib.ptr(rows), _lib.ptr(pb), _lib.ptr(slotw), _lib.ptr(xsteps),
+                                     _lib.ptr(counters), _lib.stream_ptr()))
+        return (hdr, tgt, rows, pb, slotw, xsteps, counters, bounds, key, ucap)
 
     k = (_ident(nn_index), _ident(nn_count), _ident(bin_index), F, tuple(nn_index.shape), ucap)
     return _entry(_fwd, k, build, (nn_index, nn_count, bin_index))
-
-
-def backward_plan(nn_index, nn_count, bin_index, F, N, ucap=None):
-    """-> (order, desc, rows, row_scale, pbounds, slotw, offsets, ent_key, ent_scale, ucap) or None"""
-    g = _geom.get(_ident(bin_index))
-    if g is None:
-        return None
-    database = g[0]
-    ucap = UCAP if ucap is None else int(ucap)
-    if database.shape[1] != N:
-        return None
-    B, M, K = nn_index.shape
-    offsets, ent_key, ent_scale, _active = _tgraph.transpose(nn_index, nn_count, N, bin_index=bin_index, num_bins=F)
-
-    def build():
-        dev = nn_index.device
-        order = spatial_order(database)
-        desc, rows, scale, pbounds, slotw = _tile_plan(B, N, M, F, B * M * K, True, order, offsets, ent_key, nn_count, dev,
-                                                       ucap)
-        return (order, desc, rows, scale, pbounds, slotw, offsets, ent_key, ent_scale, ucap)
-
-    k = (_ident(nn_index), _ident(nn_count), _ident(bin_index), F, tuple(nn_index.shape), int(N), ucap)
-    return _entry(_bwd, k, build, (nn_index, nn_count, bin_index, offsets, ent_key, ent_scale))

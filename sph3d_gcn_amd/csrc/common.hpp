@@ -13,7 +13,7 @@ constexpr int kRefBlock = 1024;     // its thread->work mapping defines the radi
 
 // tile plans (tile.hip -> convtile.hip): targets per candidate tile, ints per tile descriptor
 constexpr int kTileP = 16;
-constexpr int kDescInts = 1 + 2 * kTileP;
+constexpr int kSlotWords = 64;     // slot words (4 byte-sized LDS slots each) a light target may have: one wave register
 
 // ---- host-side status plumbing ------------------------------------------------
 void set_error(const char* fmt, ...);   // stores a thread-local message (api.cpp)

@@ -14,10 +14,11 @@
 //     coalesced float4 store per point.  A "slice" is 256 output channels; wider layers loop slices.
 //   * The filter table slice (F x 256 floats = 33 KB at F=33) lives in LDS, read as ds_read_b128.
 //   * Backward fuses both gradients in ONE pass over the TRANSPOSED graph (graph.hip): grad_input is a
-//     gather (registers, one store per element, no float atomics to memory), grad_filter accumulates in an
-//     LDS table with ds_add_f32 (bank-conflict-free permuted layout), flushed once per workgroup.  The
-//     reference scattered grad_input with one global atomicAdd per (point, neighbour, channel) and re-ran
-//     the whole gather ceil(F*C*r/12288) times for grad_filter (tf_conv3d_gpu.cu:51, 126-139).
+//     gather (registers, one store per element, no float atomics to memory), grad_filter accumulates in
+//     per-lane REGISTER tables (one row per bin, compile-time indexed: the transposed graph is sorted by
+//     (source, bin)), summed across waves / workgroups at the end.  The reference scattered grad_input with
+//     one global atomicAdd per (point, neighbour, channel) and re-ran the whole gather ceil(F*C*r/12288)
+//     times for grad_filter (tf_conv3d_gpu.cu:51, 126-139).
 //   * Workgroups of one cloud are dealt to one XCD (xcd_decode) so the cloud's feature rows
 //     (N*C*4 B, 4 MiB at N=8192,C=128) stay in that XCD's 4 MiB L2.
 //   * Numerics: sum_k in*filt in fp32 FMA order k = 0..cnt-1, one division by cnt at the end (the
@@ -96,7 +97,8 @@ __global__ __launch_bounds__(256) void dwconv_fwd_multi(
             // the row's neighbour ids and bin ids: ONE coalesced 256-B read each (lane k holds slot kt + k) ...
             const int myk = kt + lane;
             const int idxv = myk < cnt ? nnIndex[row * K + myk] : 0;
-            const int binv = myk < cnt ? binIndex[row * K + myk] : 0;
+            int binv = myk < cnt ? binIndex[row * K + myk] : 0;
+            binv = binv < 0 ? 0 : (binv >= F ? F - 1 : binv);     // out-of-range bin ids: same clamp as the transposed graph
             const int kn = (cnt - kt) < 64 ? (cnt - kt) : 64;
             // ... then consumed SB wave loads (SB*EPL edges) at a time: all their gathers are in flight before the
             // first FMA (the kernel is latency-bound otherwise)
@@ -209,7 +211,8 @@ __global__ __launch_bounds__(256) void dwconv_fwd_row(
             // the row's neighbour ids and bin ids: ONE coalesced 256-B read each (lane k holds slot kt + k) ...
             const int myk = kt + lane;
             const int idxv = myk < cnt ? nnIndex[row * K + myk] : 0;
-            const int binv = myk < cnt ? binIndex[row * K + myk] : 0;
+            int binv = myk < cnt ? binIndex[row * K + myk] : 0;
+            binv = binv < 0 ? 0 : (binv >= F ? F - 1 : binv);     // out-of-range bin ids: same clamp as the transposed graph
             const int kn = (cnt - kt) < 64 ? (cnt - kt) : 64;
             // ... then consumed eight at a time: 8 lane->scalar broadcasts, 8 independent row gathers and 8 filter
             // reads are in flight before the first FMA (the kernel is latency-bound otherwise)
@@ -309,7 +312,8 @@ __global__ __launch_bounds__(256) void dwconv_fwd_generic(
 #pragma unroll 4
             for (int kk = 0; kk < cnt; kk++) {
                 const int n = irow[kk];
-                const int f = brow[kk];
+                int f = brow[kk];
+                f = f < 0 ? 0 : (f >= F ? F - 1 : f);
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     const float x = inb[(size_t)n * C + cin[t]];

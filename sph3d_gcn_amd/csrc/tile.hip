@@ -10,11 +10,9 @@
 //   2. sph3d_rows_by_bin     the forward graph as a binned CSR: per output point its edges sorted by bin (the
 //                            consumer sums the rows of one bin, then multiplies by the filter row ONCE per bin:
 //                            6 edges per (point, bin) group on S3DIS-like data -> 6x fewer filter reads and FMAs);
-//                            the gradient kernels already have this form (graph.hip: in-edges sorted by (source, bin));
 //   3. sph3d_tile_plan       tiles of kTileP consecutive targets: the tile's distinct source rows (ulist) and, per
 //                            edge, the slot of its row inside the tile.  A tile whose union exceeds the LDS capacity
-//                            is split (16 -> 8 -> ... -> 1 targets); a single target that still does not fit
-//                            (in-degree > capacity in the transposed graph) is marked "direct" and gathered from memory.
+//                            is split (16 -> 8 -> ... -> 1 targets).
 // Everything here is integer work on the graph stream; results do not depend on the order (a tile only decides which
 // rows are staged together; the summation order of a target is fixed by its CSR).
 #include "common.hpp"
@@ -149,28 +147,33 @@ __global__ __launch_bounds__(256) void rows_by_bin_kernel(int rows_total, int K,
 
 // ---------------------------------------------------------------------------------------------------------------
 // 3. tile plan.  Candidate tile = kTileP consecutive positions of `order` (identity when null).  One 256-thread
-//    workgroup per candidate: bitmap of the referenced source rows in LDS -> union size; split in halves until every
-//    sub-tile fits `ucap` rows; then ranks by prefix popcounts -> ulist (and 1/count per listed row for the gradient
-//    kernel, which stages pre-scaled rows) and slot[e] for every edge of the tile's targets.
-//    desc[cand][0] = targets per sub-tile g; desc[cand][1+2s] = rows of sub-tile s (-1: direct), [2+2s] = first ulist entry.
+//    workgroup per candidate:
+//      * a target whose own edge list does not fit (more edges than `ucap` rows or than kSlotWords slot words: only
+//        when a caller asks for a tiny capacity, K <= 64 <= ucap otherwise) leaves the tile and becomes a "direct" step
+//        of its own; light targets come first in the tile's target list;
+//      * bitmap of the source rows the light targets reference (LDS) -> union size; the light list is split in
+//        halves until every sub-tile fits `ucap` rows;
+//      * ranks by prefix popcounts -> row list and, per (target, bin) group, the slots of its rows: bytes, padded to whole words with the
+//        zero row.
+//    EVERYTHING the consumer needs for the first sub-tile of a candidate sits at an address computed from the
+//    candidate index alone (so that it can be fetched two tiles ahead with no dependent load):
+//      hdr[cand]            = { targets, rows } of the first light sub-tile
+//      rows[cand*ucap + i]  its row list
+//      tgt[cand*16 + i]     target ids, light first
+//      pb[(cand*16+i)*(F+2)] word bounds of target i's bins inside its slot slab (F+1 values), then its edge count
+//      slotw[(cand*16+i)*kSlotWords + j]
+//    Further light sub-tiles of a split candidate and the direct steps are appended (atomically, any order) to the
+//    cloud's extra-step list xsteps[b] = { cand, first target, targets, rows | -1, first row entry, 0, 0, 0 }, their
+//    row lists to the pool behind the fixed part of `rows`.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool SHARED_BOUNDS>
-__device__ __forceinline__ void target_range(const int* __restrict__ bounds, int b, int T, int F, int t, int& e0, int& e1)
+__device__ __forceinline__ const int* target_bounds(const int* __restrict__ bounds, int b, int T, int F, int t)
 {
-    if (SHARED_BOUNDS) {          // graph.hip layout: offsets[b*(T*F+1) + t*F + f], end of bin F-1 = next target's bin 0
-        const int* o = bounds + (size_t)b * ((size_t)T * F + 1) + (size_t)t * F;
-        e0 = o[0];
-        e1 = o[F];
-    } else {                       // rows_by_bin layout: F+1 bounds per target
-        const int* o = bounds + ((size_t)b * T + t) * (F + 1);
-        e0 = o[0];
-        e1 = o[F];
-    }
+    return bounds + ((size_t)b * T + t) * (F + 1);          // rows_by_bin layout: F+1 bounds per target
 }
 
-// marks the source rows of targets [p0, p1) in the LDS bitmap, fills the exclusive prefix popcounts and returns the union
-// size (workgroup-uniform); 256 threads
-__device__ __forceinline__ int plan_build(unsigned* lbits, unsigned* lpre, int* scan, int W, const int* __restrict__ key,
+// marks the source rows of list entries [p0, p1) in the LDS bitmap, fills the exclusive prefix popcounts and returns the
+// union size (workgroup-uniform); 256 threads
+__device__ __forceinline__ int plan_build(unsigned* lbits, unsigned* lpre, int* wsum, int W, const int* __restrict__ key,
                                           const int* te0, const int* te1, int p0, int p1)
 {
     const int tid = (int)threadIdx.x;
@@ -188,15 +191,16 @@ __device__ __forceinline__ int plan_build(unsigned* lbits, unsigned* lpre, int* 
         const int i = tid * per + j;
         if (i < W) s += __popc(lbits[i]);
     }
-    scan[tid] = s;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        const int a = tid >= o ? scan[tid - o] : 0;
-        __syncthreads();
-        scan[tid] += a;
-        __syncthreads();
+    int incl = s;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(incl, o);
+        if ((tid & 63) >= o) incl += u;
     }
-    int run = scan[tid] - s;
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int run = incl - s;
+    for (int w = 0; w < (tid >> 6); w++) run += wsum[w];
+    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     for (int j = 0; j < per; j++) {
         const int i = tid * per + j;
         if (i < W) {
@@ -204,84 +208,129 @@ __device__ __forceinline__ int plan_build(unsigned* lbits, unsigned* lpre, int* 
             run += __popc(lbits[i]);
         }
     }
-    const int total = scan[255];
     __syncthreads();
     return total;
 }
 
-template <bool SHARED_BOUNDS>
 __global__ __launch_bounds__(256) void tile_plan_kernel(int B, int T, int NS, int F, int cands, int ucap,
                                                         const int* __restrict__ order, const int* __restrict__ bounds,
-                                                        const int* __restrict__ key, const int* __restrict__ keyCount,
-                                                        int* __restrict__ desc, int* __restrict__ ulist,
-                                                        float* __restrict__ uscale, int* __restrict__ pbounds,
-                                                        unsigned char* __restrict__ slot8, int* __restrict__ pool)
+                                                        const int* __restrict__ key,
+                                                        int* __restrict__ hdr, int* __restrict__ tgtOut,
+                                                        int* __restrict__ ulist,
+                                                        int* __restrict__ pb, unsigned char* __restrict__ slot8,
+                                                        int* __restrict__ xsteps, int* __restrict__ counters)
 {
     extern __shared__ unsigned lbits[];           // [W] bitmap, then [W] exclusive prefix popcounts
-    __shared__ int scan[256];
-    __shared__ int tgt[kTileP], te0[kTileP], te1[kTileP], subU[kTileP], subOff[kTileP];
-    __shared__ int sh_alloc;
+    __shared__ int wsum[4];
+    __shared__ int rawT[kTileP], rawE0[kTileP], rawE1[kTileP], rawW[kTileP];
+    __shared__ int tgt[kTileP], te0[kTileP], te1[kTileP];
+    __shared__ int subU[kTileP], subOff[kTileP];
+    __shared__ int sh_nl, sh_alloc, sh_xbase;
     const int W = (NS + 31) >> 5;
     unsigned* lpre = lbits + W;
     const int tid = (int)threadIdx.x;
+    const int wave = uniform(tid >> 6);
+    const int lane = lane_id();
     const int b = (int)blockIdx.x / cands, c = (int)blockIdx.x % cands;
+    const size_t cand = (size_t)b * cands + c;
     const int pos0 = c * kTileP;
     const int npts = (T - pos0) < kTileP ? (T - pos0) : kTileP;
-    if (tid < kTileP) {
-        int e0 = 0, e1 = 0, t = 0;
-        if (tid < npts) {
-            t = order ? order[(size_t)b * T + pos0 + tid] : pos0 + tid;
-            target_range<SHARED_BOUNDS>(bounds, b, T, F, t, e0, e1);
+    const int hv = ucap;
+    // every target of the candidate: edge range and number of slot words (one wave per target)
+    for (int p = wave; p < kTileP; p += 4) {
+        int e0 = 0, e1 = 0, t = 0, words = 0;
+        if (p < npts) {
+            t = order ? order[(size_t)b * T + pos0 + p] : pos0 + p;
+            const int* o = target_bounds(bounds, b, T, F, t);
+            const int ov = o[lane <= F ? lane : F];
+            const int nx = __shfl_down(ov, 1);
+            int pad = lane < F ? ((nx - ov + 3) >> 2) : 0;
+            for (int q = 32; q > 0; q >>= 1) pad += __shfl_xor(pad, q);
+            words = pad;
+            e0 = __builtin_amdgcn_readfirstlane(ov);
+            e1 = __builtin_amdgcn_readlane(ov, F);
         }
-        tgt[tid] = t;
-        te0[tid] = e0;
-        te1[tid] = e1;
+        if (lane == 0) {
+            rawT[p] = t;
+            rawE0[p] = e0;
+            rawE1[p] = e1;
+            rawW[p] = words;
+        }
     }
     __syncthreads();
+    if (tid == 0) {          // stable partition: light targets first
+        int k = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            for (int i = 0; i < npts; i++) {
+                const bool h = (rawE1[i] - rawE0[i]) > hv || rawW[i] > kSlotWords;
+                if (h == (pass == 1)) {
+                    tgt[k] = rawT[i];
+                    te0[k] = rawE0[i];
+                    te1[k] = rawE1[i];
+                    k++;
+                }
+            }
+            if (pass == 0) sh_nl = k;
+        }
+    }
+    __syncthreads();
+    const int nl = sh_nl;
+    if (tid < kTileP) tgtOut[cand * kTileP + tid] = tid < npts ? tgt[tid] : 0;
 
-    // largest sub-tile size whose unions all fit
+    // largest sub-tile size of the light list whose unions all fit
     int g = kTileP;
     for (;;) {
         bool ok = true;
-        for (int s = 0; s * g < npts; s++) {
-            const int p1 = ((s + 1) * g) < npts ? ((s + 1) * g) : npts;
-            const int U = plan_build(lbits, lpre, scan, W, key, te0, te1, s * g, p1);
+        for (int s = 0; s * g < nl; s++) {
+            const int p1 = ((s + 1) * g) < nl ? ((s + 1) * g) : nl;
+            const int U = plan_build(lbits, lpre, wsum, W, key, te0, te1, s * g, p1);
             if (tid == 0) subU[s] = U;
             if (U > ucap) {
                 ok = false;
-                if (g > 1) break;
+                break;
             }
         }
-        if (ok || g == 1) break;
+        if (ok || g == 1) break;      // g == 1 always fits: a light target has at most min(heavy, ucap) edges
         g >>= 1;
     }
     __syncthreads();
-    const int nsub = (npts + g - 1) / g;
+    const int nsubL = (nl + g - 1) / g;
+    const int nextra = (nsubL > 1 ? nsubL - 1 : 0) + (npts - nl);
     if (tid == 0) {
         int tot = 0;
-        for (int s = 0; s < nsub; s++) {
-            const int U = subU[s];
+        for (int s = 1; s < nsubL; s++) {
             subOff[s] = tot;
-            if (U <= ucap) tot += U;
+            tot += subU[s];
         }
-        sh_alloc = atomicAdd(&pool[0], tot);
+        sh_alloc = tot ? atomicAdd(&counters[0], tot) : 0;
+        sh_xbase = nextra ? atomicAdd(&counters[1 + b], nextra) : 0;
+        hdr[cand * 2 + 0] = nsubL ? (g < nl ? g : nl) : 0;
+        hdr[cand * 2 + 1] = nsubL ? subU[0] : 0;
     }
     __syncthreads();
-    int* d = desc + ((size_t)b * cands + c) * kDescInts;
-    if (tid == 0) d[0] = g;
-    if (tid < kTileP) {
-        const bool have = tid < nsub;
-        const bool direct = have && subU[tid] > ucap;
-        d[1 + 2 * tid] = have ? (direct ? -1 : subU[tid]) : 0;
-        d[2 + 2 * tid] = have ? sh_alloc + subOff[tid] : 0;
+    const size_t poolBase = (size_t)B * cands * ucap;
+    int* xs = xsteps + ((size_t)b * cands * kTileP + sh_xbase) * 8;
+    if (tid < nextra) {
+        int q0, cnt, U, uoff;
+        if (tid < nsubL - 1) {               // further light sub-tiles
+            const int s = tid + 1;
+            q0 = s * g;
+            cnt = ((s + 1) * g < nl ? (s + 1) * g : nl) - q0;
+            U = subU[s];
+            uoff = (int)(poolBase + sh_alloc + subOff[s]);
+        } else {                             // heavy targets
+            q0 = nl + (tid - (nsubL > 1 ? nsubL - 1 : 0));
+            cnt = 1;
+            U = -1;
+            uoff = 0;
+        }
+        int* r = xs + tid * 8;
+        r[0] = c; r[1] = q0; r[2] = cnt; r[3] = U; r[4] = uoff; r[5] = 0; r[6] = 0; r[7] = 0;
     }
-    const int wave = uniform(tid >> 6);
-    const int lane = lane_id();
-    for (int s = 0; s < nsub; s++) {
-        if (subU[s] > ucap) continue;               // direct sub-tile: the consumer gathers from memory by key
-        const int p0 = s * g, p1 = ((s + 1) * g) < npts ? ((s + 1) * g) : npts;
-        if (nsub > 1 || g < kTileP) plan_build(lbits, lpre, scan, W, key, te0, te1, p0, p1);   // else: still in LDS from the search
-        const int uoff = sh_alloc + subOff[s];
+    for (int s = 0; s < nsubL; s++) {
+        const int p0 = s * g, p1 = ((s + 1) * g) < nl ? ((s + 1) * g) : nl;
+        if (nsubL > 1) plan_build(lbits, lpre, wsum, W, key, te0, te1, p0, p1);      // else: still in LDS from the search
+        const size_t uoff = s == 0 ? cand * ucap : poolBase + sh_alloc + subOff[s];
         for (int i = tid; i < W; i += 256) {
             unsigned bits = lbits[i];
             int r = (int)lpre[i];
@@ -290,15 +339,11 @@ __global__ __launch_bounds__(256) void tile_plan_kernel(int B, int T, int NS, in
                 bits &= bits - 1;
                 const int n = (i << 5) + bit;
                 ulist[uoff + r] = n;
-                if (uscale) uscale[uoff + r] = 1.0f / (float)keyCount[(size_t)b * NS + n];
                 r++;
             }
         }
-        // slot bytes: one wave per target; each (target, bin) group padded to a multiple of 4 (pad = the zero row `ucap`)
         for (int p = p0 + wave; p < p1; p += 4) {
-            const int t = tgt[p];
-            const int* __restrict__ o = SHARED_BOUNDS ? bounds + (size_t)b * ((size_t)T * F + 1) + (size_t)t * F
-                                                      : bounds + ((size_t)b * T + t) * (F + 1);
+            const int* o = target_bounds(bounds, b, T, F, tgt[p]);
             const int ov = o[lane <= F ? lane : F];
             const int nx = __shfl_down(ov, 1);
             const int len = lane < F ? nx - ov : 0;
@@ -308,29 +353,28 @@ __global__ __launch_bounds__(256) void tile_plan_kernel(int B, int T, int NS, in
                 const int u = __shfl_up(incl, q);
                 if (lane >= q) incl += u;
             }
-            const int total = __builtin_amdgcn_readlane(incl, 63);
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&pool[1], total);
-            base = uniform(base);
-            const int dstart = base + incl - pad;
-            if (lane <= F) pbounds[((size_t)b * T + t) * (F + 1) + lane] = dstart;
-            unsigned long long mask = __ballot(len > 0);
-            while (mask) {
-                const int f = (int)__builtin_ctzll(mask);
-                mask &= mask - 1;
-                const int e0 = __builtin_amdgcn_readlane(ov, f);
-                const int L = __builtin_amdgcn_readlane(len, f);
-                const int d0 = __builtin_amdgcn_readlane(dstart, f);
-                const int P4 = ((L + 3) >> 2) << 2;
-                for (int j = lane; j < P4; j += 64) {
-                    int v = ucap;
-                    if (j < L) {
-                        const int n = key[e0 + j];
-                        v = (int)lpre[n >> 5] + __popc(lbits[n >> 5] & ((1u << (n & 31)) - 1u));
-                    }
-                    slot8[(size_t)4 * d0 + j] = (unsigned char)v;
+            const int dstart = incl - pad;                       // first slot word of this lane's group, inside the slab
+            const int e_begin = __builtin_amdgcn_readfirstlane(ov);
+            const int e_end = __builtin_amdgcn_readlane(ov, F);
+            const size_t tp = cand * kTileP + p;
+            if (lane <= F + 1) pb[tp * (F + 2) + lane] = lane <= F ? dstart : (e_end - e_begin);
+            unsigned char* slab = slot8 + tp * (kSlotWords * 4);
+            for (int eb = e_begin; eb < e_end; eb += 64) {
+                const int e = eb + lane;
+                const bool valid = e < e_end;
+                const int n = valid ? key[e] : 0;
+                int f = 0;                                   // bin of edge e: the last group whose start is <= e
+                for (int j = 1; j < F; j++) {
+                    const int bj = __builtin_amdgcn_readlane(ov, j);
+                    f = e >= bj ? j : f;
                 }
+                const int gs = __shfl(ov, f);
+                const int ds = __shfl(dstart, f);
+                const int v = (int)lpre[n >> 5] + __popc(lbits[n >> 5] & ((1u << (n & 31)) - 1u));
+                if (valid) slab[4 * ds + (e - gs)] = (unsigned char)v;
             }
+            if (lane < F)
+                for (int j = len; j < 4 * pad; j++) slab[4 * dstart + j] = (unsigned char)ucap;
         }
         __syncthreads();
     }
@@ -370,41 +414,43 @@ extern "C" int sph3d_rows_by_bin(int B, int M, int K, int F, const int* nn_index
     return check_launch("sph3d_rows_by_bin");
 }
 
-extern "C" int sph3d_tile_plan_sizes(int B, int T, int F, long long E, int* n_cands, size_t* desc_ints, size_t* rows_ints,
-                                     size_t* pbounds_ints, size_t* slot_words)
+extern "C" int sph3d_tile_plan_sizes(int B, int T, int F, int ucap, long long E, int* n_cands, size_t* hdr_ints,
+                                     size_t* tgt_ints, size_t* rows_ints, size_t* pb_ints, size_t* slot_words,
+                                     size_t* xstep_ints, size_t* counter_ints)
 {
     const int cands = (T + kTileP - 1) / kTileP;
     if (n_cands) *n_cands = cands;
-    if (desc_ints) *desc_ints = (size_t)B * cands * kDescInts;
-    if (rows_ints) *rows_ints = (size_t)(E > 0 ? E : 1) + 64;          // sum of the unions <= number of edges
-    if (pbounds_ints) *pbounds_ints = (size_t)B * T * (F + 1);
-    // every non-empty group wastes < 4 bytes and there are <= min(E, T*F) groups: words <= (E + 3 min(E, B*T*F)) / 4 <= E
-    if (slot_words) *slot_words = (size_t)(E > 0 ? E : 1) + 64;
+    if (hdr_ints) *hdr_ints = (size_t)B * cands * 2;
+    if (tgt_ints) *tgt_ints = (size_t)B * cands * kTileP;
+    // fixed part (ucap per candidate) + pool for the further sub-tiles (sum of the unions <= number of edges) + read-ahead slack
+    if (rows_ints) *rows_ints = (size_t)B * cands * ucap + (size_t)(E > 0 ? E : 1) + 256;
+    if (pb_ints) *pb_ints = (size_t)B * cands * kTileP * (F + 2);
+    if (slot_words) *slot_words = (size_t)B * cands * kTileP * kSlotWords;
+    if (xstep_ints) *xstep_ints = (size_t)B * cands * kTileP * 8;
+    if (counter_ints) *counter_ints = (size_t)B + 1;
     return SPH3D_OK;
 }
 
-extern "C" int sph3d_tile_plan(int B, int T, int NS, int F, int shared_bounds, int ucap,
-                               const int* order, const int* bounds, const int* key, const int* key_count,
-                               int* tile_desc, int* tile_rows, float* tile_row_scale, int* pbounds, int* slot_words,
-                               int* pool_counter, sph3d_stream_t stream)
+extern "C" int sph3d_tile_plan(int B, int T, int NS, int F, int ucap,
+                               const int* order, const int* bounds, const int* key,
+                               int* tile_hdr, int* tile_targets, int* tile_rows, int* tile_pb,
+                               int* slot_words, int* extra_steps, int* counters, sph3d_stream_t stream)
 {
-    SPH3D_REQUIRE(B >= 0 && T > 0 && NS > 0 && F > 0 && F <= 63, "tile_plan: bad dims B=%d T=%d NS=%d F=%d", B, T, NS, F);
+    SPH3D_REQUIRE(B >= 0 && T > 0 && NS > 0 && F > 0 && F <= 62, "tile_plan: bad dims B=%d T=%d NS=%d F=%d", B, T, NS, F);
     SPH3D_REQUIRE(ucap >= 4 && ucap <= 252 && ucap % 4 == 0, "tile_plan: ucap=%d must be a multiple of 4 in [4, 252]", ucap);
-    SPH3D_REQUIRE(tile_row_scale == nullptr || key_count != nullptr, "tile_plan: tile_row_scale needs key_count");
     if (B == 0) return SPH3D_OK;
     const int cands = (T + kTileP - 1) / kTileP;
     const size_t lds = sizeof(unsigned) * 2 * (size_t)((NS + 31) >> 5);
     SPH3D_REQUIRE(lds <= 150 * 1024, "tile_plan: %d source rows do not fit the LDS bitmap", NS);
     hipStream_t st = as_stream(stream);
-    int rc = check_hip(hipMemsetAsync(pool_counter, 0, 2 * sizeof(int), st), "tile_plan: memset");
+    int rc = check_hip(hipMemsetAsync(counters, 0, ((size_t)B + 1) * sizeof(int), st), "tile_plan: memset");
     if (rc) return rc;
-    auto kern = shared_bounds ? tile_plan_kernel<true> : tile_plan_kernel<false>;
     if (lds > 60 * 1024) {
-        rc = check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+        rc = check_hip(hipFuncSetAttribute((const void*)tile_plan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                        "tile_plan: hipFuncSetAttribute");
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(kern, dim3(B * cands), dim3(256), lds, st, B, T, NS, F, cands, ucap, order, bounds, key, key_count, tile_desc,
-                       tile_rows, tile_row_scale, pbounds, (unsigned char*)slot_words, pool_counter);
+    hipLaunchKernelGGL(tile_plan_kernel, dim3(B * cands), dim3(256), lds, st, B, T, NS, F, cands, ucap, order, bounds, key,
+                       tile_hdr, tile_targets, tile_rows, tile_pb, (unsigned char*)slot_words, extra_steps, counters);
     return check_launch("sph3d_tile_plan");
 }

@@ -117,7 +117,13 @@ class GraphPlan:
                 ev_xyz.record(s_fps)
                 self._sampling_chain(s_fps)
             s_graph.wait_event(ev_xyz)
-            xyz.record_stream(s_graph)
+            # every tensor the sampling stream allocated is read by kernels on the graph stream (neighbour search,
+            # binning, pooled-row gathers): tell the caching allocator, or their blocks return to the sampling stream's
+            # pool when the plan is dropped and the NEXT step's sampling (which only waits for its input batch) may
+            # overwrite them while this step's graph kernels still read them
+            for t in self.xyz_layers + self.indices:
+                if torch.is_tensor(t):
+                    t.record_stream(s_graph)
             with torch.cuda.stream(s_graph):
                 self._build_all(s_graph)
         else:

@@ -48,14 +48,13 @@ def _depthwise_conv3d_impl(input: torch.Tensor, filter: torch.Tensor, nn_index: 
         out = _depthwise_conv3d_impl(Fn.pad(input, (0, pad)), Fn.pad(filter, (0, 0, 0, pad)), nn_index, nn_count, bin_index)
         return out[:, :, :C * r].contiguous()
     output = torch.empty((B, M, C * r), dtype=torch.float32, device=input.device)
-    plan = _plan.forward_plan(nn_index, nn_count, bin_index, F) if _plan.eligible(N, M, K, F, C, r) else None
+    plan = _plan.forward_plan(nn_index, nn_count, bin_index, F) if _plan.applies(N, M, K, F, C, r) else None
     if plan is not None:
-        # LDS-tiled kernel: the graph's tile plan exists (its coordinates were registered by spherical_kernel)
-        order, desc, rows, pbounds, slotw, bounds, key, ucap = plan
+        # LDS-tiled kernel: the caller asked for it and the graph's tile plan can be built (coordinates registered)
+        hdr, tgt, rows, pb, slotw, xsteps, counters, _bounds, _key, ucap = plan
         _lib.check(_lib.lib().sph3d_depthwise_conv3d_tiled(
-            B, N, M, F, C, r, ucap, _plan.variant(), _lib.ptr(order), _lib.ptr(desc), _lib.ptr(rows), _lib.ptr(pbounds),
-            _lib.ptr(slotw), _lib.ptr(nn_count), _lib.ptr(bounds), _lib.ptr(key),
-            _lib.ptr(input), _lib.ptr(filter), _lib.ptr(output), _lib.stream_ptr()))
+            B, N, M, F, C, r, ucap, _lib.ptr(hdr), _lib.ptr(tgt), _lib.ptr(rows), _lib.ptr(pb), _lib.ptr(slotw),
+            _lib.ptr(xsteps), _lib.ptr(counters), _lib.ptr(input), _lib.ptr(filter), _lib.ptr(output), _lib.stream_ptr()))
         return output
     _lib.check(_lib.lib().sph3d_depthwise_conv3d(
         B, N, M, F, C, r, K, _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(bin_index),
@@ -88,20 +87,9 @@ def _depthwise_conv3d_grad_impl(input: torch.Tensor, filter: torch.Tensor, grad_
         return gi[:, :, :C].contiguous(), gf[:, :C, :].contiguous()
     grad_input = torch.empty_like(input)
     grad_filter = torch.empty_like(filter)
-    l = _lib.lib()
-    plan = _plan.backward_plan(nn_index, nn_count, bin_index, F, N) if _plan.eligible(N, M, K, F, C, r) else None
-    if plan is not None:
-        order, desc, rows, row_scale, pbounds, slotw, offsets, ent_key, ent_scale, ucap = plan
-        wsb = l.sph3d_depthwise_conv3d_grad_tiled_workspace(F, C, r, _plan.variant())
-        ws = torch.empty((wsb,), dtype=torch.uint8, device=input.device)
-        _lib.check(l.sph3d_depthwise_conv3d_grad_tiled(
-            B, N, M, F, C, r, ucap, _plan.variant(), _lib.ptr(order), _lib.ptr(desc), _lib.ptr(rows), _lib.ptr(row_scale),
-            _lib.ptr(pbounds), _lib.ptr(slotw), _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale),
-            _lib.ptr(input), _lib.ptr(filter), _lib.ptr(grad_output), _lib.ptr(grad_input), _lib.ptr(grad_filter),
-            _lib.ptr(ws), wsb, _lib.stream_ptr()))
-        return grad_input, grad_filter
     # gather over the transposed graph (built once per graph, shared by every gradient that uses it)
     offsets, ent_key, ent_scale, active = _tgraph.transpose(nn_index, nn_count, N, bin_index=bin_index, num_bins=F)
+    l = _lib.lib()
     wsb = l.sph3d_depthwise_conv3d_grad_t_workspace(B, N, F, C, r)
     ws = torch.empty((wsb,), dtype=torch.uint8, device=input.device) if wsb else None
     _lib.check(l.sph3d_depthwise_conv3d_grad_t(

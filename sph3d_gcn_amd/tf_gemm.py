@@ -1,34 +1,13 @@
 """Pointwise 1x1 feature GEMM — the ``tf.matmul`` inside separable_conv3d / pointwise_conv3d /
 fully_connected (utils/sph3gcn_util.py:146-150, 204-206, 260; cuBLAS SGEMM in the reference).
 
-``matmul(x, w)`` computes x[R,Cin] @ w[Cin,Cout] in exact fp32.  Backends:
-  * "hip"  — libsph3d's hand-written fp32-MFMA kernel (sph3d_pointwise_gemm*), custom op
-             ``sph3d::pointwise_gemm`` with its two backward products;
-  * "blas" — torch.matmul (rocBLAS / hipBLASLt), the library yardstick.
-Select with set_backend() or the SPH3D_GEMM environment variable.
+``matmul(x, w)`` computes x[R,Cin] @ w[Cin,Cout] in exact fp32 with libsph3d's hand-written fp32-MFMA kernels
+(sph3d_pointwise_gemm*): custom op ``sph3d::pointwise_gemm`` with its two backward products.  (The library yardstick,
+torch.matmul on rocBLAS / hipBLASLt, lives in tools/exp_gemm.py, not here.)
 """
-import os
-
 import torch
 
 from . import _lib
-
-_backend = os.environ.get("SPH3D_GEMM", "hip")
-
-
-def set_backend(name):
-    global _backend
-    if name not in ("hip", "blas"):
-        raise ValueError("unknown GEMM backend %r" % (name,))
-    _backend = name
-
-
-def get_backend():
-    return _backend
-
-
-def _have_hip_gemm():
-    return hasattr(_lib.lib(), "sph3d_pointwise_gemm")
 
 
 def _pointwise_gemm_impl(x: torch.Tensor, w: torch.Tensor, trans_w: bool) -> torch.Tensor:
@@ -107,6 +86,4 @@ class _PointwiseGemmFn(torch.autograd.Function):      # eager fast path (see tf_
 
 
 def matmul(x, w):
-    if _backend == "hip":
-        return _PointwiseGemmFn.apply(x, w)
-    return torch.matmul(x, w)
+    return _PointwiseGemmFn.apply(x, w)
