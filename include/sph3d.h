@@ -75,12 +75,20 @@ int sph3d_build_cube_neighbor(int B, int N, int M, int grid_size, int nn_sample,
  * kernel build_spherical_kernel :20-79; op SphericalKernel tf_buildkernel.cpp:35-99).
  * -> filt_index[B,M,K] i32: 0 = self / unused slot, else
  * 1 + nID + n*pID + n*p*qID.  Requires n>2 even, p>0 even, q>0 (:39-49).
- * atan2f is include/sph3d_atan2f.h on device and in the oracle. */
+ * atan2f is include/sph3d_atan2f.h (correctly rounded, the same bits on device and in the CPU oracle).
+ * sph3d_spherical_kernel_ocml is the same kernel calling ROCm's device-library atan2f: bit-for-bit the bins the
+ * reference's own kernel produces when built for this GPU; they differ from the default only for neighbours within an
+ * ulp of an angular bin boundary and are not reproducible on a CPU. */
 int sph3d_spherical_kernel(int B, int N, int M, int K, int n, int p, int q, float radius,
                            const float* database, const float* query,
                            const int* nn_index, const int* nn_count, const float* nn_dist,
                            int* filt_index,
                            sph3d_stream_t stream);
+int sph3d_spherical_kernel_ocml(int B, int N, int M, int K, int n, int p, int q, float radius,
+                                const float* database, const float* query,
+                                const int* nn_index, const int* nn_count, const float* nn_dist,
+                                int* filt_index,
+                                sph3d_stream_t stream);
 
 /* ---- convolution --------------------------------------------------------
  * replaces depthwiseConv3dLauncher (tf_ops/convolution/tf_conv3d_gpu.cu:107-113;

@@ -26,6 +26,7 @@ SIGNATURES = {
     "sph3d_build_sphere_neighbor": (_I, [_I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "sph3d_build_cube_neighbor": (_I, [_I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P]),
     "sph3d_spherical_kernel": (_I, [_I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "sph3d_spherical_kernel_ocml": (_I, [_I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
     "sph3d_depthwise_conv3d": (_I, [_I] * 7 + [_P] * 7),
     "sph3d_depthwise_conv3d_grad_workspace": (_S, [_I] * 7),
     "sph3d_depthwise_conv3d_grad": (_I, [_I] * 7 + [_P] * 8 + [_P, _S, _P]),

@@ -9,7 +9,11 @@
 // Bit-exactness notes (must match oracle_sphere_bin):
 //   * M_PI in the reference is the glibc double macro, so the clamp / shift / divide-by-pi steps run in
 //     double and round to float on assignment; reproduced literally below.
-//   * atan2f is include/sph3d_atan2f.h (shared with the oracle), not ocml.
+//   * atan2f is include/sph3d_atan2f.h (shared with the oracle: correctly rounded, identical on host and device), so
+//     that the bins are reproducible on a CPU.  OCML = true (sph3d_spherical_kernel_ocml) calls ROCm's device-library
+//     atan2f instead: bit-for-bit the bins of the reference's own kernel as it builds on this stack (oracle/_ref),
+//     which differ from the default on neighbours that sit within an ulp of a 45-degree boundary (16 of 262 144
+//     entries on 3-cm-grid data; pinned in tests/golden/ref_gfx950.json).
 //   * built with -ffp-contract=off.
 #include "common.hpp"
 #include "../../include/sph3d_atan2f.h"
@@ -18,14 +22,15 @@ namespace sph3d {
 
 #define SPH3D_PI 3.14159265358979323846   // double, == glibc M_PI
 
+template <bool OCML>
 __device__ __forceinline__ int sphere_bin(float dx, float dy, float dz, float dist, float radius, int n, int p, int q)
 {
     const float M_EPSf = 1.01e-3F;                                     // tf_buildkernel_gpu.cu:5-7
     float dist2D = dx * dx + dy * dy;                                  // :49
     dist2D = sqrtf(dist2D);                                            // :50
     if (!(dist > M_EPSf && (double)fabsf(dist - M_EPSf) > 1e-6)) return 0;   // :52-53 self / coincident
-    float theta = sph3d_atan2f(dy, dx);                                // :55
-    float phi = sph3d_atan2f(dz, dist2D);                              // :56
+    float theta = OCML ? atan2f(dy, dx) : sph3d_atan2f(dy, dx);        // :55
+    float phi = OCML ? atan2f(dz, dist2D) : sph3d_atan2f(dz, dist2D);  // :56
     theta = (float)((double)theta < SPH3D_PI ? (double)theta : -SPH3D_PI);        // :58
     theta = (float)((double)theta > -SPH3D_PI ? (double)theta : -SPH3D_PI);       // :59
     theta = (float)((double)theta + SPH3D_PI);                                    // :60
@@ -41,6 +46,7 @@ __device__ __forceinline__ int sphere_bin(float dx, float dy, float dz, float di
     return qID * p * n + pID * n + nID + 1;                                       // :74
 }
 
+template <bool OCML>
 __global__ __launch_bounds__(256) void spherical_kernel_kernel(
     int B, int N, int M, int K, int n, int p, int q, float radius,
     const float* __restrict__ database, const float* __restrict__ query,
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(256) void spherical_kernel_kernel(
             const float dx = pt[0] - qp[0];
             const float dy = pt[1] - qp[1];
             const float dz = pt[2] - qp[2];
-            out = sphere_bin(dx, dy, dz, nnDist[e], radius, n, p, q);
+            out = sphere_bin<OCML>(dx, dy, dz, nnDist[e], radius, n, p, q);
         }
         filtIndex[e] = out;
     }
@@ -76,17 +82,17 @@ __global__ void selftest_math_kernel(int n, const float* a, const float* b, floa
     out_atan2[i] = sph3d_atan2f(a[i], b[i]);
     out_sqrt[i] = sqrtf(fabsf(a[i]));
     out_div[i] = a[i] / b[i];
-    out_bin[i] = sphere_bin(a[i], b[i], a[i] * b[i], sqrtf(sqrtf(a[i] * a[i] + b[i] * b[i])), 0.1f, 8, 2, 2);
+    out_bin[i] = sphere_bin<false>(a[i], b[i], a[i] * b[i], sqrtf(sqrtf(a[i] * a[i] + b[i] * b[i])), 0.1f, 8, 2, 2);
 }
 
 }  // namespace sph3d
 
 using namespace sph3d;
 
-extern "C" int sph3d_spherical_kernel(int B, int N, int M, int K, int n, int p, int q, float radius,
-                                      const float* database, const float* query,
-                                      const int* nn_index, const int* nn_count, const float* nn_dist,
-                                      int* filt_index, sph3d_stream_t stream)
+static int spherical_kernel_launch(bool ocml, int B, int N, int M, int K, int n, int p, int q, float radius,
+                                   const float* database, const float* query,
+                                   const int* nn_index, const int* nn_count, const float* nn_dist,
+                                   int* filt_index, sph3d_stream_t stream)
 {
     SPH3D_REQUIRE(radius > 0, "Range search requires radius>0, got %g", (double)radius);   // tf_buildkernel.cpp:40
     SPH3D_REQUIRE(n > 2 && n % 2 == 0, "Need n_>2 and n_%%2==0, got %d", n);               // :43
@@ -97,9 +103,31 @@ extern "C" int sph3d_spherical_kernel(int B, int N, int M, int K, int n, int p, 
     if (total == 0) return SPH3D_OK;
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(spherical_kernel_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
-                       B, N, M, K, n, p, q, radius, database, query, nn_index, nn_count, nn_dist, filt_index);
+    if (ocml)
+        hipLaunchKernelGGL(spherical_kernel_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                           B, N, M, K, n, p, q, radius, database, query, nn_index, nn_count, nn_dist, filt_index);
+    else
+        hipLaunchKernelGGL(spherical_kernel_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                           B, N, M, K, n, p, q, radius, database, query, nn_index, nn_count, nn_dist, filt_index);
     return check_launch("sph3d_spherical_kernel");
+}
+
+extern "C" int sph3d_spherical_kernel(int B, int N, int M, int K, int n, int p, int q, float radius,
+                                      const float* database, const float* query,
+                                      const int* nn_index, const int* nn_count, const float* nn_dist,
+                                      int* filt_index, sph3d_stream_t stream)
+{
+    return spherical_kernel_launch(false, B, N, M, K, n, p, q, radius, database, query, nn_index, nn_count, nn_dist, filt_index,
+                                   stream);
+}
+
+extern "C" int sph3d_spherical_kernel_ocml(int B, int N, int M, int K, int n, int p, int q, float radius,
+                                           const float* database, const float* query,
+                                           const int* nn_index, const int* nn_count, const float* nn_dist,
+                                           int* filt_index, sph3d_stream_t stream)
+{
+    return spherical_kernel_launch(true, B, N, M, K, n, p, q, radius, database, query, nn_index, nn_count, nn_dist, filt_index,
+                                   stream);
 }
 
 // not part of the reference surface: device-side evaluation of the shared scalar math (tests only)

@@ -1,10 +1,25 @@
 """Spherical-kernel bin assignment — mirrors tf_ops/buildkernel/tf_buildkernel.py:10-34.
 
 PyTorch custom op ``sph3d::spherical_kernel`` (no gradient, :34).
+
+``set_atan2("ocml")`` switches the angle function from the shared correctly-rounded atan2f (default: the same bits on
+the GPU and in the CPU oracle) to ROCm's device-library atan2f — the function the reference's own kernel calls when it
+is built for this GPU.  In that mode the bins equal the reference build's bit for bit (tests/test_gpu_parity.py); in
+the default mode they differ from it only for neighbours within an ulp of an angular bin boundary (the exact list on
+the golden clouds is pinned in tests/golden/ref_gfx950.json).
 """
 import torch
 
 from . import _lib, _plan
+
+_atan2 = "shared"
+
+
+def set_atan2(which):
+    global _atan2
+    if which not in ("shared", "ocml"):
+        raise ValueError("atan2 must be 'shared' or 'ocml'")
+    _atan2 = which
 
 
 def _spherical_kernel_impl(database: torch.Tensor, query: torch.Tensor, nn_index: torch.Tensor,
@@ -24,7 +39,9 @@ def _spherical_kernel_impl(database: torch.Tensor, query: torch.Tensor, nn_index
     M = query.shape[1]
     K = nn_index.shape[2]
     filt_index = torch.empty((B, M, K), dtype=torch.int32, device=database.device)
-    _lib.check(_lib.lib().sph3d_spherical_kernel(
+    l = _lib.lib()
+    fn = l.sph3d_spherical_kernel_ocml if _atan2 == "ocml" else l.sph3d_spherical_kernel
+    _lib.check(fn(
         B, N, M, K, n_azim, p_elev, q_radi, radius, _lib.ptr(database), _lib.ptr(query),
         _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(nn_dist), _lib.ptr(filt_index), _lib.stream_ptr()))
     # the convolutions that will use these bins can tile their work spatially: remember which coordinates they came from
