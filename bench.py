@@ -3,16 +3,20 @@
 SPH3D_s3dis-shaped network on 8192-point S3DIS-like blocks, 16 blocks per GPU (weak scaling).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+  (N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank
+   per GPU, or run plainly — without WORLD_SIZE in the environment the script re-launches itself that way)
 
 A "step" = graph construction (nnquery, FPS, buildkernel: they depend on the input xyz, so they are part
 of every step) + forward + loss + backward + gradient all-reduce (N > 1) + optimiser update, on one batch
-of synthetic blocks already resident in HBM.  Rank 0 prints ONE JSON line (contract in the task brief),
-with two extra objects:
-  roofline     — the dominant libsph3d kernel of the timed region: algorithmic bytes (SURVEY §8d formulas)
-                 / its mean device time measured with HIP events on the launching stream during the timed steps;
-  cpu_baseline — the same harness step on the CPU oracle (oracle/, OpenMP over all host cores) on a bounded
-                 sample of the same workload; rank 0, N = 1 only.
+of synthetic blocks already resident in HBM (two different batches alternate, so nothing a step computes can be
+left over from the step before).  Rank 0 prints ONE JSON line (contract in the task brief), with two extra objects:
+  roofline     — the dominant libsph3d op family of the step (GEMM NN / NT / TN count as one family): algorithmic
+                 bytes or flops of its largest call (SURVEY §8d formulas) / that call's mean device time, measured
+                 with HIP events on the launching stream (avg_us: inside the running step, other streams busy;
+                 isolated_us: the same call alone on an idle GPU; trace_us: the kernel's duration in the committed
+                 rocprofv3 trace of the same command, when profiles/ holds one);
+  cpu_baseline — the same harness step on the CPU oracle (oracle/, OpenMP) on a bounded sample of the same
+                 workload, at all host threads (median of 10 steps) and at one thread; rank 0, N = 1 only.
 """
 import argparse
 import json
@@ -90,8 +94,11 @@ def algorithmic_bytes(name, a):
     return 0
 
 
-def make_batch(rank, dev):
-    first = 1000 + rank * BLOCKS_PER_GPU
+NUM_BATCHES = 2            # distinct resident batches, used in turn
+
+
+def make_batch(rank, dev, which=0):
+    first = 1000 + (which * 64 + rank) * BLOCKS_PER_GPU
     xyz, label, inner = synth.s3dis_batch(first, BLOCKS_PER_GPU, NUM_POINT)
     return (torch.from_numpy(xyz).to(dev), torch.from_numpy(label).to(dev), torch.from_numpy(inner).to(dev))
 
@@ -144,70 +151,174 @@ class GraphedStep:
         return self.loss
 
 
-def cpu_baseline(sample_blocks=4, budget_s=30.0):
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sample_blocks=2, timed_steps=10, warm_steps=3, budget_s=40.0):
     """Same harness step (graph build + fwd + bwd + Adam) on the CPU oracle — kind = "port": oracle/ is the C
     restatement of the reference's kernels, OpenMP across independent work items; GEMM / BN / ELU run in torch-CPU
-    (MKL/oneDNN) so the baseline is not handicapped.  Bounded sample: `sample_blocks` S3DIS-like blocks per step; one
-    untimed step creates the variables, then one timed step per candidate thread count (all hardware threads, physical
-    cores, half of them) and the fastest is reported with the thread count it used."""
+    (MKL/oneDNN) so the baseline is not handicapped.  Bounded sample: `sample_blocks` S3DIS-like 8192-point blocks per
+    step.  Protocol: a short probe picks the faster of {all hardware threads, physical cores}; then
+    `warm_steps` untimed + `timed_steps` timed steps at that thread count, MEDIAN reported; then one block at ONE thread
+    (1 untimed step was already taken; as many timed steps as fit the remaining budget, at least one)."""
     import oracle  # noqa: F401  (cpu_baseline leg: the oracle is the thing timed here, by design)
     from oracle import torch_ops
     hw = os.cpu_count() or 1
     phys = hw // 2 if hw >= 16 else hw
-    cands = []
-    for c in (phys, hw, max(1, phys // 2)):
-        if c not in cands:
-            cands.append(c)
+    cands = [hw] if phys == hw else [phys, hw]
     xyz, label, inner = synth.s3dis_batch(5000, sample_blocks, NUM_POINT)
     pts, label, inner = torch.from_numpy(xyz), torch.from_numpy(label), torch.from_numpy(inner)
     t_start = time.perf_counter()
-    best = None
+
+    def set_threads(c):
+        oracle.set_num_threads(c)
+        torch.set_num_threads(c)
+
     with torch_ops.patched_util():
         model = s3dis_net.SPH3DS3DIS(s3dis_net.s3dis_config(NUM_POINT), device=torch.device("cpu"))
-        oracle.set_num_threads(cands[0])
-        torch.set_num_threads(cands[0])
+        set_threads(cands[0])
         pred, _ = model(pts, is_training=True)
         model.loss(pred, label, inner).backward()                       # cold step: creates the variables
         flat = hdist.FlatGradAllReduce(model.parameters())
         opt = torch.optim.Adam([flat.flat_param], lr=1e-3, eps=1e-4)
-        for c in cands:
-            if best is not None and (time.perf_counter() - t_start) > budget_s:
-                break
-            oracle.set_num_threads(c)
-            torch.set_num_threads(c)
+
+        def timed(p, l, i):
             t0 = time.perf_counter()
-            train_step(model, flat, opt, pts, label, inner)
-            el = time.perf_counter() - t0
-            if best is None or el < best[0]:
-                best = (el, c)
-    el, c = best
-    return {"value": round(sample_blocks / el, 4), "unit": "blocks/s", "cores": c, "kind": "port",
-            "sample": "1 timed step x %d S3DIS-like 8192-pt blocks (full SPH3D_s3dis graph build + fwd + bwd + Adam on "
-                      "oracle/ C+OpenMP, torch-CPU GEMM/BN), best of thread counts %s on a %d-thread host, %.2f s/step"
-                      % (sample_blocks, cands, hw, el)}
+            train_step(model, flat, opt, p, l, i)
+            return time.perf_counter() - t0
+
+        probe = {}
+        for c in cands:
+            set_threads(c)
+            timed(pts, label, inner)
+            probe[c] = timed(pts, label, inner)
+        best_c = min(probe, key=probe.get)
+        set_threads(best_c)
+        for _ in range(warm_steps):
+            timed(pts, label, inner)
+        times = [timed(pts, label, inner) for _ in range(timed_steps)]
+        med = float(np.median(times))
+        # one thread, one block
+        set_threads(1)
+        p1, l1, i1 = pts[:1], label[:1], inner[:1]
+        timed(p1, l1, i1)
+        t1 = [timed(p1, l1, i1)]
+        while (time.perf_counter() - t_start) + t1[-1] < budget_s and len(t1) < 5:
+            t1.append(timed(p1, l1, i1))
+        med1 = float(np.median(t1))
+    return {"value": round(sample_blocks / med, 4), "unit": "blocks/s", "cores": best_c, "kind": "port",
+            "cpu": _cpu_model(), "host_threads": hw,
+            "steps": {"warmup": warm_steps, "timed": timed_steps, "median_s": round(med, 4),
+                      "min_s": round(min(times), 4), "max_s": round(max(times), 4),
+                      "probe_s_per_thread_count": {str(k): round(v, 4) for k, v in probe.items()}},
+            "one_thread": {"value": round(1.0 / med1, 4), "unit": "blocks/s", "blocks_per_step": 1,
+                           "timed_steps": len(t1), "median_s": round(med1, 4)},
+            "sample": "%d S3DIS-like 8192-pt blocks per step (full SPH3D_s3dis graph build + fwd + bwd + Adam on oracle/ "
+                      "C99+OpenMP, torch-CPU GEMM/BN): median of %d steps after %d warm-up steps at %d threads"
+                      % (sample_blocks, timed_steps, warm_steps, best_c)}
+
+
+def isolated_call_seconds(name, ints, dev, reps=20):
+    """mean device time of ONE C-ABI call of the given op and dims, alone on an idle GPU (synthetic operands)"""
+    from sph3d_gcn_amd import tf_gemm, tf_conv3d, tf_nnquery, tf_buildkernel
+    try:
+        if "gemm" in name:
+            R_, Ci_, Co_ = ints[:3]
+            x = torch.randn(R_, Ci_, device=dev)
+            w = torch.randn(Ci_, Co_, device=dev)
+            dy = torch.randn(R_, Co_, device=dev)
+            if name.endswith("_tn"):
+                fn = lambda: tf_gemm._pointwise_gemm_tn_impl(x, dy)
+            else:
+                fn = lambda: tf_gemm._pointwise_gemm_impl(x, w, False)
+        elif name in ("sph3d_depthwise_conv3d", "sph3d_depthwise_conv3d_grad_t"):
+            if name == "sph3d_depthwise_conv3d":
+                B, N, M, F, C, r, K = ints[:7]
+            else:
+                B, N, M, F, C, r = ints[:6]
+                K = 64
+            if N != M:
+                return None
+            radius = {8192: 0.1, 2048: 0.2, 768: 0.4, 384: 0.8, 128: 1.6}.get(N, 0.1)
+            xyz = torch.from_numpy(synth.s3dis_batch(1000, B, NUM_POINT)[0]).to(dev)
+            from sph3d_gcn_amd import tf_sample
+            while xyz.shape[1] > N:
+                nxt = {8192: 2048, 2048: 768, 768: 384, 384: 128}[xyz.shape[1]]
+                idx = tf_sample.farthest_point_sample(nxt, xyz)
+                xyz = torch.gather(xyz, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+            nidx, cnt, dst = tf_nnquery.build_sphere_neighbor(xyz, xyz, radius, None, K)
+            filt = tf_buildkernel.spherical_kernel(xyz, xyz, nidx, cnt, dst, radius, [8, 2, 2])
+            x = torch.randn(B, N, C, device=dev)
+            w = torch.randn(F, C, r, device=dev)
+            go = torch.randn(B, M, C * r, device=dev)
+            if name == "sph3d_depthwise_conv3d":
+                fn = lambda: tf_conv3d.depthwise_conv3d(x, w, nidx, cnt, filt)
+            else:
+                fn = lambda: tf_conv3d.depthwise_conv3d_grad(x, w, go, nidx, cnt, filt)
+        else:
+            return None
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps / 1e3
+    except Exception as e:                      # a measurement aid, never a reason to lose the bench line
+        sys.stderr.write("isolated timing of %s failed: %s\n" % (name, e))
+        return None
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` with no launcher: re-run this script under torch.distributed.run, one rank per GPU"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hipgraph", action="store_true", help="capture fwd+bwd into a HIP graph and replay it (experimental)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(args))
     rank, world, local_rank = hdist.init_from_env()
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert world == args.gpus, "launched with WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback in the product path)"
+    assert torch.cuda.device_count() >= (local_rank + 1), "rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     _lib.lib()
 
-    pts, label, inner = make_batch(rank, dev)
+    batches = [make_batch(rank, dev, w) for w in range(NUM_BATCHES)]
     torch.cuda.synchronize()
     ev = torch.cuda.Event()
     ev.record()
-    _PTS_READY[pts.data_ptr()] = ev
+    for bt in batches:
+        _PTS_READY[bt[0].data_ptr()] = ev
+    pts, label, inner = batches[0]
+    step_no = [0]
     model = s3dis_net.SPH3DS3DIS(s3dis_net.s3dis_config(NUM_POINT), device=dev)
     # variables are created by the first forward (TF-style scopes): one untimed pass, then flat buffers + Adam
     graphs = s3dis_net.build_graphs(pts, model.config)
@@ -236,7 +347,9 @@ def main():
     def one_step():
         if graphed is not None:
             return graphed.step(opt)
-        return train_step(model, flat, opt, pts, label, inner)
+        p_, l_, i_ = batches[step_no[0] % NUM_BATCHES]        # a different resident batch every step
+        step_no[0] += 1
+        return train_step(model, flat, opt, p_, l_, i_)
 
     # Priming (setup, not measurement): the first ~14 steps of a fresh process contain one-off host stalls — the caching
     # allocator still growing its pools (hipMalloc is synchronous) and one 80-90 ms pause at the 14th step (first
@@ -262,9 +375,10 @@ def main():
     # data, same kernels), with every C-ABI launch bracketed by two HIP events on its launching stream.  They are
     # not recorded inside the timed region because the eager step is host-bound and ~460 extra event records per
     # step would lengthen the very interval being measured.
+    ev_steps = min(args.steps, 20)
     _lib.timing_start()
-    for _ in range(args.steps):
-        train_step(model, flat, opt, pts, label, inner)
+    for _ in range(ev_steps):
+        one_step()
     torch.cuda.synchronize()
     events = _lib.timing_stop()
 
@@ -286,46 +400,57 @@ def main():
     for (name, ints), (ms, cnt) in ranked[:8]:
         ab = algorithmic_bytes(name, ints)
         avg_ms = ms / cnt
-        kernels.append({"op": name, "dims": list(ints[:7]), "calls_per_step": cnt / args.steps,
-                        "avg_us": round(avg_ms * 1e3, 1), "ms_per_step": round(ms / args.steps, 3),
+        kernels.append({"op": name, "dims": list(ints[:7]), "calls_per_step": cnt / ev_steps,
+                        "avg_us": round(avg_ms * 1e3, 1), "ms_per_step": round(ms / ev_steps, 3),
                         "alg_GB": round(ab / 1e9, 4), "GBps": round(ab / 1e9 / (avg_ms / 1e3), 1) if avg_ms > 0 else None})
     # dominant kernel = the op family with the largest summed device time on the main stream (the FPS chain runs
     # on a side stream, overlapped, and is latency-bound: it is reported in `kernels`, not as the roofline kernel);
     # the roofline numbers are those of that family's largest call
+    def family(name):
+        return "sph3d_pointwise_gemm*" if "gemm" in name else name
+
     fam = {}
     for (name, ints), (ms, cnt) in per.items():
         if name == "sph3d_farthest_point_sample":
             continue
-        f = fam.setdefault(name, [0.0, None, 0.0])
+        f = fam.setdefault(family(name), [0.0, None, 0.0])
         f[0] += ms
         if ms / cnt > f[2]:
             f[1], f[2] = (name, ints, ms, cnt), ms / cnt
     roofline = None
+    families = {k: round(v[0] / ev_steps, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
     if fam:
         fname = max(fam, key=lambda k: fam[k][0])
         name, ints, ms, cnt = fam[fname][1]
         ab = algorithmic_bytes(name, ints)
         avg_s = ms / cnt / 1e3
         is_gemm = "gemm" in name
+        iso_s = isolated_call_seconds(name, ints, dev)
         if is_gemm:
             R_, Ci_, Co_ = ints[:3]
-            achieved = 2.0 * R_ * Ci_ * Co_ / 1e12 / avg_s
-            peak, unit, bound = FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", "mfma"
+            work, peak, unit, bound = 2.0 * R_ * Ci_ * Co_ / 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", "mfma"
         else:
-            achieved = ab / 1e9 / avg_s
-            peak, unit, bound = HBM_PEAK_GBS, "GB/s", "hbm"
-        traffic = None
+            work, peak, unit, bound = ab / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
+        achieved = work / avg_s
+        traffic, trace_us = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 table = json.load(open(tpath))
-                traffic = table.get("%s%s" % (name, list(ints[:7])), table.get("%s%s" % (name, list(ints[:6]))))
+                key = "%s%s" % (name, list(ints[:7]))
+                traffic = table.get(key, table.get("%s%s" % (name, list(ints[:6]))))
+                trace_us = table.get("trace_us", {}).get(key)
             except Exception:
                 traffic = None
-        roofline = {"kernel": name, "dims": list(ints[:7]), "bound": bound, "achieved": round(achieved, 1),
+        roofline = {"kernel": name, "family": fname, "dims": list(ints[:7]), "bound": bound, "achieved": round(achieved, 1),
                     "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
-                    "alg_bytes": ab, "avg_us": round(avg_s * 1e6, 1), "traffic": traffic,
-                    "family_ms_per_step": round(fam[fname][0] / args.steps, 3)}
+                    "alg_bytes": ab, "avg_us": round(avg_s * 1e6, 1),
+                    "isolated_us": round(iso_s * 1e6, 1) if iso_s else None,
+                    "isolated_frac": round(work / iso_s / peak, 4) if iso_s else None,
+                    "trace_us": trace_us, "traffic": traffic,
+                    "family_ms_per_step": round(fam[fname][0] / ev_steps, 3),
+                    "note": "avg_us: HIP events around the C-ABI call inside the running step (three streams share the "
+                            "CUs); isolated_us: the same call alone on an idle GPU; trace_us: rocprofv3 kernel trace"}
     # the north-star "conv gather" line: depthwise forward at (B=16, N=M=8192, C=128, r=2, K=64)
     conv_gather = None
     for (name, ints), (ms, cnt) in per.items():
@@ -334,7 +459,21 @@ def main():
             avg_s = ms / cnt / 1e3
             conv_gather = {"avg_us": round(avg_s * 1e6, 1), "achieved": round(ab / 1e9 / avg_s, 1), "unit": "GB/s",
                            "frac": round(ab / 1e9 / avg_s / HBM_PEAK_GBS, 4), "alg_bytes": ab}
-    sph3d_ms = sum(v[0] for v in per.values()) / args.steps
+            iso = isolated_call_seconds(name, ints, dev)
+            if iso:
+                conv_gather["isolated_us"] = round(iso * 1e6, 1)
+                conv_gather["isolated_frac"] = round(ab / 1e9 / iso / HBM_PEAK_GBS, 4)
+            from sph3d_gcn_amd import _plan
+            _plan.set_mode("tiled")              # the LDS-tiled kernel of the same layer (opt-in: its plan costs 0.3 ms per graph)
+            try:
+                iso_t = isolated_call_seconds(name, ints, dev)
+            finally:
+                _plan.set_mode("gather")
+                _plan.clear()
+            if iso_t:
+                conv_gather["tiled_kernel_isolated_us"] = round(iso_t * 1e6, 1)
+                conv_gather["tiled_kernel_isolated_frac"] = round(ab / 1e9 / iso_t / HBM_PEAK_GBS, 4)
+    sph3d_ms = sum(v[0] for v in per.values()) / ev_steps
 
     if rank == 0:
         blocks = world * BLOCKS_PER_GPU * args.steps
@@ -354,10 +493,13 @@ def main():
             "config": {"workload": "SPH3D_s3dis seg net (s3dis_config.py plan), S3DIS-like 8192-pt blocks, "
                                    "%d blocks/GPU, graph build + fwd + bwd + Adam" % BLOCKS_PER_GPU,
                        "global_batch": world * BLOCKS_PER_GPU, "points_per_block": NUM_POINT,
-                       "parallelism": "dp%d (one cloud shard per GPU, one flat RCCL grad all-reduce)" % world,
+                       "parallelism": "dp%d (one cloud shard per GPU; flat gradient all-reduced over RCCL in %d buckets, "
+                                      "overlapped with backward)" % (world, len(flat.buckets)),
+                       "resident_batches": NUM_BATCHES, "event_pass_steps": ev_steps,
                        "params": nparams, "launch_mode": mode},
             "loss": round(float(loss), 5),
-            "sph3d_kernels_ms_per_step": round(sph3d_ms, 3),
+            "sph3d_calls_ms_per_step_summed_over_streams": round(sph3d_ms, 3),
+            "families_ms_per_step": families,
             "roofline": roofline,
             "conv_gather": conv_gather,
             "kernels": kernels,

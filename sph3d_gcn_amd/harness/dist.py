@@ -1,5 +1,5 @@
-"""Data-parallel plumbing: one process per GPU, batch sharded by cloud, ONE flat gradient all-reduce per
-step (the reference is single-GPU).  Every op of the path is independent per cloud, so the
+"""Data-parallel plumbing: one process per GPU, batch sharded by cloud, the flat gradient all-reduced in a few
+multi-MiB buckets overlapped with the backward pass (the reference is single-GPU).  Every op of the path is independent per cloud, so the
 forward/backward data path has no collective; only the parameter gradient is summed (RCCL over xGMI:
 backend "nccl" on ROCm; "gloo" in the CPU tests)."""
 import os
@@ -30,12 +30,20 @@ def shard_range(total, rank, world):
 
 
 class FlatGradAllReduce:
-    """All parameters and all gradients live in two flat fp32 buffers (the nn.Parameters are views), so
-    the step's collective is a single all-reduce of ~15 MiB for the S3DIS net — one large message per step
-    suits xGMI's per-link-bound ring — and the optimiser update is one elementwise kernel over
-    ``flat_param`` (pass ``[self.flat_param]`` to the optimiser)."""
+    """All parameters and all gradients live in two flat fp32 buffers (the nn.Parameters are views), the optimiser
+    update is one elementwise kernel over ``flat_param`` (pass ``[self.flat_param]`` to the optimiser), and the
+    gradient sum over the replicas is bucketed and overlapped with the backward pass:
 
-    def __init__(self, params):
+      * the parameters are cut into buckets of >= ``bucket_bytes`` in creation order (= forward order);
+      * ``backward(loss)`` takes the gradients with torch.autograd.grad; tensor hooks on the parameters collect them, and
+        as soon as the LAST gradient of a bucket exists (the backward pass reaches the buckets in reverse order) the
+        bucket is written into the flat buffer with one concatenation and its all-reduce is started (RCCL over xGMI: backend "nccl"
+        on ROCm; "gloo" in the CPU tests) asynchronously on the process group's stream;
+      * ``all_reduce()`` waits for the outstanding buckets before the optimiser step.
+    xGMI rings are per-link bound, so a bucket is several MiB (default 4 MiB: 4 buckets for the 15-MiB S3DIS net); with
+    one replica no collective is issued and the hooks only do the concatenations."""
+
+    def __init__(self, params, bucket_bytes=4 << 20):
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
@@ -43,33 +51,81 @@ class FlatGradAllReduce:
         self.flat_param = torch.nn.Parameter(torch.empty(n, dtype=torch.float32, device=dev))
         self.flat_param.grad = self.flat
         off = 0
+        self.buckets = []                      # (first param index, one past last, flat begin, flat end)
+        b_first, b_off = 0, 0
         with torch.no_grad():
-            for p in self.params:
+            for i, p in enumerate(self.params):
                 k = p.numel()
                 self.flat_param.data[off:off + k].copy_(p.data.reshape(-1))
                 p.data = self.flat_param.data[off:off + k].view_as(p)
-                p.grad = self.flat[off:off + k].view_as(p)
+                p.grad = None
                 off += k
+                if (off - b_off) * 4 >= bucket_bytes or i == len(self.params) - 1:
+                    self.buckets.append((b_first, i + 1, b_off, off))
+                    b_first, b_off = i + 1, off
+        self._pending = []
+        self._done = set()
+        self._got = [dict() for _ in self.buckets]        # per bucket: parameter index -> gradient of this backward pass
+        self._armed = False
+        for bi, (i0, i1, f0, f1) in enumerate(self.buckets):
+            for i in range(i0, i1):
+                self.params[i].register_hook(self._make_hook(bi, i))
+
+    def _world(self):
+        return dist.get_world_size() if dist.is_initialized() else 1
+
+    def _finish_bucket(self, bi, grads):
+        i0, i1, f0, f1 = self.buckets[bi]
+        parts = [(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(grads, self.params[i0:i1])]
+        view = self.flat[f0:f1]
+        torch.cat(parts, out=view)
+        if self._world() > 1:
+            self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+        self._done.add(bi)
+
+    def _make_hook(self, bi, i):
+        def hook(grad):
+            if not self._armed:                 # a backward pass that is not ours (e.g. the variable-creating first step)
+                return
+            got = self._got[bi]
+            got[i] = grad
+            i0, i1, _f0, _f1 = self.buckets[bi]
+            if len(got) == i1 - i0:
+                self._finish_bucket(bi, [got[j] for j in range(i0, i1)])
+                got.clear()
+        return hook
 
     def broadcast_params(self, src=0):
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if self._world() > 1:
             dist.broadcast(self.flat_param.data, src=src)
 
     def zero(self):
         self.flat.zero_()
 
     def backward(self, loss):
-        """loss.backward() for the flat layout: the parameter gradients are taken with torch.autograd.grad and written
-        into the flat buffer by ONE concatenation.  (Through the .grad views every parameter costs its own in-place `add`
-        launch — 69 of them, 0.35 ms of 5-us kernels per S3DIS step — and the buffer must be zeroed first.)"""
-        grads = torch.autograd.grad(loss, self.params, allow_unused=True)
-        parts = [(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(grads, self.params)]
-        torch.cat(parts, out=self.flat)
+        """loss.backward() for the flat layout: gradients by torch.autograd.grad, written into the flat buffer one bucket
+        at a time as the backward pass produces them (one concatenation per bucket — through .grad views every parameter
+        would cost its own in-place `add` launch: 69 of them, 0.35 ms of 5-us kernels per S3DIS step), each bucket's
+        all-reduce started at once."""
+        self._done.clear()
+        for got in self._got:
+            got.clear()
+        self._armed = True
+        try:
+            grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+        finally:
+            self._armed = False
+        for bi, (i0, i1, f0, f1) in enumerate(self.buckets):       # buckets with parameters the loss does not depend on
+            if bi not in self._done:
+                self._finish_bucket(bi, grads[i0:i1])
+            self._got[bi].clear()
         return self.flat
 
     def all_reduce(self, average=False):
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            if average:
-                self.flat.div_(dist.get_world_size())
+        """wait for the bucket all-reduces started during backward()"""
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+        if average and self._world() > 1:
+            self.flat.div_(self._world())
         return self.flat
