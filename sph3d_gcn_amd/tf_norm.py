@@ -69,6 +69,10 @@ def _(y, dout, gamma, save_mean, save_rstd, training):
     return torch.empty_like(y), torch.empty_like(gamma), torch.empty_like(gamma)
 
 
+# (sph3d::elu_bn updates the moving statistics in place, so the dispatcher accepts no autograd formula for it: the
+# gradient wiring of the fused tail is _EluBnFn below, over the functional sph3d::elu_bn_grad.)
+
+
 class _EluBnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, gamma, beta, moving_mean, moving_var, training):

@@ -46,7 +46,10 @@ def farthest_point_sample(neursize, database):
 
 
 def inverse_density_sample(neursize, probability):
-    '''Gumbel-max top-k over log(probability) (tf_sample.py:27-41).'''
+    '''Gumbel-max top-k over log(probability) (tf_sample.py:27-41): `neursize` DISTINCT points per cloud, point i drawn
+    with weight probability[i] (build_graph passes the mean sqrt-distance to the neighbours, i.e. sparse regions are
+    favoured).  Entries that are not positive and finite (a row whose neighbour count is 0 gives 0/0) get weight zero.'''
+    probability = torch.where(torch.isfinite(probability) & (probability > 0), probability, torch.zeros_like(probability))
     logits = torch.log(probability)
     u = torch.rand_like(logits)
     z = -torch.log(-torch.log(u))
