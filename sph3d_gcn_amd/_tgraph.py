@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 
-_MAX_ENTRIES = 48
+_MAX_ENTRIES = 16      # one S3DIS step builds 12 (8 binned intra graphs + 4 inter graphs); entries pin ~150 MB each at level 0
 _cache = collections.OrderedDict()
 
 

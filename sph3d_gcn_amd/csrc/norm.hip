@@ -113,8 +113,10 @@ __device__ __forceinline__ void sum_partials_32x8(int C, int nblk, const float* 
     }
 }
 
-// forward finalize: mean / rstd from the partials (double), running statistics update (torch / TF convention:
-// running = (1-m)*running + m*batch, running_var with the unbiased batch variance)
+// forward finalize: mean / rstd from the partials (double), running statistics update
+// running = (1-m)*running + m*batch with the BIASED batch variance: tf.layers.batch_normalization on rank-2/3 inputs takes
+// the non-fused path (tf.nn.moments), which stores the population variance — torch's F.batch_norm would store the
+// Bessel-corrected one (3 % larger at the ModelNet fc layers, where R = batch size)
 __global__ __launch_bounds__(1024) void norm_fwd_finalize(int R, int C, int nblk, const float* __restrict__ partial, float eps, float momentum,
                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
                                   float* __restrict__ run_var)
@@ -130,9 +132,8 @@ __global__ __launch_bounds__(1024) void norm_fwd_finalize(int R, int C, int nblk
     mean[c] = (float)m;
     rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
     if (run_mean != nullptr) {
-        const double unb = R > 1 ? var * ((double)R / (R - 1)) : var;
         run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * m);
-        run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unb);
+        run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * var);
     }
 }
 

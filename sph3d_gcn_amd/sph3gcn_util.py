@@ -338,5 +338,14 @@ def batch_normalization(data, is_training, name, reuse=None):
     gamma, beta, moving_mean, moving_var = _bn_variables(store, name, C)
     training = True if is_training is None else bool(is_training)
     flat = data.reshape(-1, C)
-    out = F.batch_norm(flat, moving_mean, moving_var, gamma, beta, training=training, momentum=1.0 - 0.99, eps=1e-3)
+    if training:
+        # batch statistics for the output; the moving statistics take the BIASED batch variance, as the non-fused
+        # tf.layers path (tf.nn.moments) does — F.batch_norm would store the Bessel-corrected one
+        out = F.batch_norm(flat, None, None, gamma, beta, training=True, momentum=0.0, eps=1e-3)
+        with torch.no_grad():
+            var, mean = torch.var_mean(flat, dim=0, unbiased=False)
+            moving_mean.mul_(0.99).add_(mean, alpha=1.0 - 0.99)
+            moving_var.mul_(0.99).add_(var, alpha=1.0 - 0.99)
+    else:
+        out = F.batch_norm(flat, moving_mean, moving_var, gamma, beta, training=False, momentum=0.0, eps=1e-3)
     return out.reshape(data.shape)

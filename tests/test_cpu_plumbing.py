@@ -95,6 +95,8 @@ def test_batch_norm_matches_tf_layers_semantics():
         torch.testing.assert_close(y, (x - mean) / torch.sqrt(var + 1e-3), rtol=1e-4, atol=1e-4)
         mm = store.get_buffer('bn0/moving_mean', (6,), 0.0)
         torch.testing.assert_close(mm, 0.01 * mean, rtol=1e-4, atol=1e-5)      # momentum 0.99
+        mv = store.get_buffer('bn0/moving_variance', (6,), 1.0)
+        torch.testing.assert_close(mv, 0.99 + 0.01 * var, rtol=1e-5, atol=1e-6)  # biased variance, as tf.nn.moments
         y2 = s3g_util.batch_normalization(x, False, 'bn0')
         assert torch.isfinite(y2).all()
     assert store.regularization_loss() is not None     # gamma/beta l2 regularisers registered

@@ -1,0 +1,166 @@
+"""The BASELINE.json configurations at FULL size on the HIP path: size-independent properties over the whole outputs plus
+oracle checks on slices the CPU finishes in seconds.
+
+  config 2  ModelNet40 cls, 32 x 10 000 points, full SPH3D_modelnet plan, forward + backward
+  config 3  ShapeNet part-seg, 64 x 2048 points, full encoder-decoder plan, forward + backward
+  config 4  S3DIS seg, 16 x 8192-point blocks per GPU (the bench workload), forward + backward
+  config 5  ScanNet stress, one 65 536-point block: neighbour graph, bins, depthwise conv forward + gradients, max-pool,
+            un-pooling at level 0 (reference "compat" semantics: the radius-growth chain saturates most rows at K)
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from sph3d_gcn_amd import tf_nnquery, tf_buildkernel, tf_conv3d, tf_pool3d, tf_unpool3d, tf_sample
+from sph3d_gcn_amd.harness import modelnet_net, shapenet_net, s3dis_net, synth
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def _n(t):
+    return t.detach().cpu().numpy()
+
+
+def _finite_grads(model):
+    n = 0
+    for name, p in model.named_parameters():
+        assert p.grad is not None, name
+        assert torch.isfinite(p.grad).all(), name
+        n += p.numel()
+    return n
+
+
+def _graph_properties(idx, cnt, K, N):
+    idx_n, cnt_n = _n(idx), _n(cnt)
+    assert cnt_n.min() >= 1 and cnt_n.max() <= K
+    valid = np.arange(K)[None, None, :] < cnt_n[:, :, None]
+    assert (np.diff(idx_n, axis=2)[valid[:, :, 1:]] > 0).all()          # ascending database index
+    assert (idx_n[~valid] == 0).all() and idx_n.min() >= 0 and idx_n.max() < N
+    return idx_n, cnt_n
+
+
+def test_modelnet_full_config(dev):
+    B, N = 32, 10000
+    cfg = modelnet_net.modelnet_config(N)
+    xyz = synth.modelnet_batch(0, B, N)
+    pts = torch.from_numpy(xyz).to(dev)
+    label = torch.randint(0, 40, (B,), generator=torch.Generator().manual_seed(0)).to(dev)
+    model = modelnet_net.SPH3DModelNet(cfg, device=dev)
+    pred, _ = model(pts, is_training=True, dropout_generator=torch.Generator().manual_seed(5))
+    assert pred.shape == (B, 40) and torch.isfinite(pred).all()
+    loss = model.loss(pred, label)
+    loss.backward()
+    assert torch.isfinite(loss) and _finite_grads(model) == 788396          # parameter count of the full plan
+    # level-0 integers of two clouds against the oracle (neighbour graph, bins, first FPS picks)
+    sl = slice(3, 5)
+    idx, cnt, dst = tf_nnquery.build_sphere_neighbor(pts[sl], pts[sl], cfg.radius[0], None, cfg.nn_uplimit[0])
+    io, co, do = oracle.build_sphere_neighbor(xyz[sl], xyz[sl], cfg.radius[0], None, cfg.nn_uplimit[0])
+    np.testing.assert_array_equal(_n(idx), io)
+    np.testing.assert_array_equal(_n(cnt), co)
+    filt = tf_buildkernel.spherical_kernel(pts[sl], pts[sl], idx, cnt, dst, cfg.radius[0], cfg.kernel)
+    np.testing.assert_array_equal(_n(filt), oracle.spherical_kernel(xyz[sl], xyz[sl], io, co, do, cfg.radius[0], cfg.kernel))
+    fps = tf_sample.farthest_point_sample(200, pts[sl])
+    np.testing.assert_array_equal(_n(fps), oracle.farthest_point_sample(200, xyz[sl]))
+
+
+def test_shapenet_full_config(dev):
+    B, N = 64, 2048
+    cfg = shapenet_net.shapenet_config(N)
+    xyz = synth.modelnet_batch(100, B, N)
+    pts = torch.from_numpy(xyz).to(dev)
+    label = torch.randint(0, 3, (B, N), generator=torch.Generator().manual_seed(1)).to(dev)
+    model = shapenet_net.SPH3DShapeNet(3, cfg, device=dev)
+    pred, _ = model(pts, is_training=True)
+    assert pred.shape == (B, N, 3) and torch.isfinite(pred).all()
+    loss = model.loss(pred, label)
+    loss.backward()
+    assert torch.isfinite(loss) and _finite_grads(model) > 3_000_000
+    sl = slice(10, 12)
+    idx, cnt, dst = tf_nnquery.build_sphere_neighbor(pts[sl], pts[sl], cfg.radius[0], None, cfg.nn_uplimit[0])
+    io, co, do = oracle.build_sphere_neighbor(xyz[sl], xyz[sl], cfg.radius[0], None, cfg.nn_uplimit[0])
+    np.testing.assert_array_equal(_n(idx), io)
+    np.testing.assert_array_equal(_n(cnt), co)
+    fps = tf_sample.farthest_point_sample(cfg.num_sample[0], pts[sl])
+    np.testing.assert_array_equal(_n(fps), oracle.farthest_point_sample(cfg.num_sample[0], xyz[sl]))
+
+
+def test_s3dis_bench_config_full_step(dev):
+    """the bench workload: 16 x 8192-point blocks, full plan (3 935 680 parameters), one forward + backward; the level-0
+    graph of the whole batch is checked by properties, two blocks of it against the oracle"""
+    B, N = 16, 8192
+    cfg = s3dis_net.s3dis_config(N)
+    xyz, label, inner = synth.s3dis_batch(1000, B, N)
+    pts = torch.from_numpy(xyz).to(dev)
+    model = s3dis_net.SPH3DS3DIS(cfg, device=dev)
+    pred, _ = model(pts, is_training=True)
+    assert pred.shape == (B, N, 13) and torch.isfinite(pred).all()
+    loss = model.loss(pred, torch.from_numpy(label).to(dev), torch.from_numpy(inner).to(dev))
+    loss.backward()
+    assert torch.isfinite(loss) and _finite_grads(model) == 3935680
+    idx, cnt, dst = tf_nnquery.build_sphere_neighbor(pts, pts, 0.1, None, 64)
+    idx_n, cnt_n = _graph_properties(idx, cnt, 64, N)
+    # NOTE the chain: with B = 16 (<= 32) every cloud starts its chains afresh, so cloud b alone reproduces rows of the batch
+    io, co, do = oracle.build_sphere_neighbor(xyz[5:6], xyz[5:6], 0.1, None, 64)
+    np.testing.assert_array_equal(idx_n[5:6], io)
+    np.testing.assert_array_equal(cnt_n[5:6], co)
+
+
+def test_scannet_65536_level0_feature_ops(dev):
+    """config 5, compat (reference) semantics: N = 65 536, K = 64, r = 0.1.  Rows 0..1023 of the level-0 graph are also
+    produced by the oracle (chain position 0); conv / pool / un-pool outputs of those rows and the gradients they induce
+    are compared with the oracle run on the same rows; everything else by properties."""
+    N, K, r, C = 65536, 64, 0.1, 64
+    xyz = synth.s3dis_batch(77, 1, N, extent=(6.0, 6.0, 3.0))[0]
+    xt = torch.from_numpy(xyz).to(dev)
+    idx, cnt, dst = tf_nnquery.build_sphere_neighbor(xt, xt, r, None, K)
+    idx_n, cnt_n = _graph_properties(idx, cnt, K, N)
+    assert (cnt_n == K).mean() > 0.5                                 # the growing radius saturates most rows
+    filt = tf_buildkernel.spherical_kernel(xt, xt, idx, cnt, dst, r, [8, 2, 2])
+    filt_n = _n(filt)
+    assert filt_n.min() >= 0 and filt_n.max() <= 32
+    S = 1024
+    io, co, do = oracle.build_sphere_neighbor(xyz, xyz[:, :S], r, None, K)
+    np.testing.assert_array_equal(idx_n[:, :S], io)
+    fo = oracle.spherical_kernel(xyz, xyz[:, :S], io, co, do, r, [8, 2, 2])
+    np.testing.assert_array_equal(filt_n[:, :S], fo)
+    rng = np.random.RandomState(0)
+    x = rng.randn(1, N, C).astype(np.float32)
+    w = rng.randn(33, C, 2).astype(np.float32)
+    xg = torch.from_numpy(x).to(dev).requires_grad_(True)
+    wg = torch.from_numpy(w).to(dev).requires_grad_(True)
+    out = tf_conv3d.depthwise_conv3d(xg, wg, idx, cnt, filt)
+    assert out.shape == (1, N, 2 * C) and torch.isfinite(out).all()
+    np.testing.assert_allclose(_n(out)[:, :S], oracle.depthwise_conv3d(x, w, io, co, fo), **TOL)
+    # gradient of a loss that only looks at the first S output rows == oracle gradient over the sliced graph
+    go = np.zeros((1, N, 2 * C), np.float32)
+    go[:, :S] = rng.randn(1, S, 2 * C)
+    out.backward(torch.from_numpy(go).to(dev))
+    gi_o, gf_o = oracle.depthwise_conv3d_grad(x, w, go[:, :S], io, co, fo)
+    np.testing.assert_allclose(_n(xg.grad), gi_o, **TOL)
+    s = max(1.0, float(np.abs(gf_o).max()))
+    np.testing.assert_allclose(_n(wg.grad) / s, gf_o / s, **TOL)
+    # max-pool to the first 16 384 FPS picks is too long a chain for a test: pool onto the first S queries' rows instead
+    xp = torch.from_numpy(x).to(dev).requires_grad_(True)
+    pooled, arg = tf_pool3d.max_pool3d(xp, idx[:, :S].contiguous(), cnt[:, :S].contiguous())
+    po, ao = oracle.max_pool3d(x, io, co)
+    np.testing.assert_array_equal(_n(pooled), po)
+    np.testing.assert_array_equal(_n(arg), ao)
+    gp = rng.randn(1, S, C).astype(np.float32)
+    pooled.backward(torch.from_numpy(gp).to(dev))
+    np.testing.assert_allclose(_n(xp.grad), oracle.max_pool3d_grad(x, gp, ao), **TOL)
+    # un-pooling: coarse set = the first S points, every fine point interpolates from its neighbours among them
+    coarse = xyz[:, :S]
+    ui, uc, ud = tf_nnquery.build_sphere_neighbor(torch.from_numpy(coarse).to(dev), xt, 0.4, None, 16)
+    cf = rng.randn(1, S, C).astype(np.float32)
+    cg = torch.from_numpy(cf).to(dev).requires_grad_(True)
+    up = tf_unpool3d.mean_interpolate(cg, ui, uc)
+    assert up.shape == (1, N, C) and torch.isfinite(up).all()
+    uio, uco, udo = oracle.build_sphere_neighbor(coarse, xyz[:, :2048], 0.4, None, 16)
+    np.testing.assert_array_equal(_n(ui)[:, :2048], uio)
+    np.testing.assert_allclose(_n(up)[:, :2048], oracle.mean_interpolate(cf, uio, uco), **TOL)
+    gu = np.zeros((1, N, C), np.float32)
+    gu[:, :2048] = rng.randn(1, 2048, C)
+    up.backward(torch.from_numpy(gu).to(dev))
+    np.testing.assert_allclose(_n(cg.grad), oracle.mean_interpolate_grad(cf, gu[:, :2048], uio, uco), **TOL)
