@@ -61,6 +61,14 @@ int sph3d_build_sphere_neighbor(int B, int N, int M, int nn_sample, float radius
                                 const float* database, const float* query,
                                 int* nn_index, int* nn_count, float* nn_dist,
                                 sph3d_stream_t stream);
+/* Same search with a FIXED radius per query — NOT the reference's semantics: every query starts from `radius` (growth by
+ * 0.05 only until it has one neighbour; nothing is carried along the reference-thread chain or from cloud to cloud).
+ * For clouds much larger than the reference's 8192-point blocks (BASELINE config 5: 65 536 points), where the chain
+ * lets the radius reach metres and saturates every row at K. */
+int sph3d_build_sphere_neighbor_fixed(int B, int N, int M, int nn_sample, float radius,
+                                const float* database, const float* query,
+                                int* nn_index, int* nn_count, float* nn_dist,
+                                sph3d_stream_t stream);
 
 /* replaces buildCubeNeighborLauncher (tf_nnquery_gpu.cu:123-127; kernel
  * cal_nn_binidx_cube :72-113; op BuildCubeNeighbor tf_nnquery.cpp:116-168).

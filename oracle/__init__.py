@@ -83,7 +83,7 @@ def _check(rc, name):
 
 
 # ---- nnquery (tf_ops/nnquery/tf_nnquery.py) -------------------------------
-def build_sphere_neighbor(database, query, radius=0.1, dilation_rate=None, nnsample=100):
+def build_sphere_neighbor(database, query, radius=0.1, dilation_rate=None, nnsample=100, fixed=False):
     database = _f(np.asarray(database)[:, :, 0:3])
     query = _f(np.asarray(query)[:, :, 0:3])
     if dilation_rate is not None:
@@ -93,8 +93,9 @@ def build_sphere_neighbor(database, query, radius=0.1, dilation_rate=None, nnsam
     idx = np.empty((B, M, nnsample), np.int32)
     cnt = np.empty((B, M), np.int32)
     dst = np.empty((B, M, nnsample), np.float32)
-    rc = lib().oracle_build_sphere_neighbor(_c_int(B), _c_int(N), _c_int(M), _c_int(nnsample), _c_float(radius),
-                                            _pf(database), _pf(query), _pi(idx), _pi(cnt), _pf(dst))
+    fn = lib().oracle_build_sphere_neighbor_fixed if fixed else lib().oracle_build_sphere_neighbor
+    rc = fn(_c_int(B), _c_int(N), _c_int(M), _c_int(nnsample), _c_float(radius),
+            _pf(database), _pf(query), _pi(idx), _pi(cnt), _pf(dst))
     _check(rc, "build_sphere_neighbor")
     return idx, cnt, dst
 

@@ -110,6 +110,59 @@ int oracle_build_sphere_neighbor(int B, int N, int M, int nnSample, float radius
     return ORACLE_OK;
 }
 
+/* Fixed-radius variant (sph3d_build_sphere_neighbor_fixed): NOT reference semantics — the radius is reset for every
+ * query, so only the growth-until-one-neighbour loop of a single query remains. */
+int oracle_build_sphere_neighbor_fixed(int B, int N, int M, int nnSample, float radius0,
+                                 const float* database, const float* query,
+                                 int* nnIndex, int* nnCount, float* nnDist)
+{
+    if (B < 0 || N <= 0 || M < 0 || nnSample <= 0 || !(radius0 > 0)) return ORACLE_EINVAL;
+    memset(nnIndex, 0, sizeof(int) * (size_t)B * M * nnSample);
+    memset(nnCount, 0, sizeof(int) * (size_t)B * M);
+    memset(nnDist, 0, sizeof(float) * (size_t)B * M * nnSample);
+    const int nb = imin(B, REF_GRID), nt = imin(M, REF_BLOCK);
+#pragma omp parallel for collapse(2) schedule(dynamic, 8)
+    for (int bb = 0; bb < nb; bb++) {
+        for (int t = 0; t < nt; t++) {
+            float radius = radius0;                       /* kernel parameter copy, per thread */
+            for (int i = bb; i < B; i += REF_GRID) {      /* :21 */
+                for (int j = t; j < M; j += REF_BLOCK) {  /* :23 */
+                    radius = radius0;                     /* the deviation: no carry along the chain */
+                    const float qx = query[(size_t)i * M * 3 + j * 3];
+                    const float qy = query[(size_t)i * M * 3 + j * 3 + 1];
+                    const float qz = query[(size_t)i * M * 3 + j * 3 + 2];
+                    int s = 0, passes = 0;
+                    int* idx = nnIndex + ((size_t)i * M + j) * nnSample;
+                    float* dst = nnDist + ((size_t)i * M + j) * nnSample;
+                    while (s == 0) {                      /* :30 */
+                        s = 0;
+                        for (int k = 0; k < N; k++) {     /* :35 */
+                            const float dx = database[(size_t)i * N * 3 + k * 3] - qx;
+                            const float dy = database[(size_t)i * N * 3 + k * 3 + 1] - qy;
+                            const float dz = database[(size_t)i * N * 3 + k * 3 + 2] - qz;
+                            float dist2D = dx * dx + dy * dy;           /* :45 */
+                            float dist3D = dist2D + dz * dz;            /* :46 */
+                            dist3D = sqrtf(dist3D);                     /* :47 */
+                            /* :49  float < float ; fabs(float) compared with the double 1e-6 */
+                            if (dist3D < radius && (double)fabsf(dist3D - radius) > 1e-6) {
+                                if (s < nnSample) {
+                                    idx[s] = k;
+                                    dst[s] = sqrtf(dist3D);             /* :54 sqrt of the distance */
+                                }
+                                s++;
+                            }
+                        }
+                        radius = (float)((double)radius + 0.05);        /* :59 float += double literal */
+                        if (++passes >= ORACLE_MAX_GROWTH_PASSES) break; /* reference would spin */
+                    }
+                    nnCount[(size_t)i * M + j] = s < nnSample ? s : nnSample; /* :62 */
+                }
+            }
+        }
+    }
+    return ORACLE_OK;
+}
+
 /* ------------------------------------------------------------------------
  * cal_nn_binidx_cube — tf_nnquery_gpu.cu:72-113 ; zero-init tf_nnquery.cpp:160-161
  * ---------------------------------------------------------------------- */

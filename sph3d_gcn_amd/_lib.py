@@ -24,6 +24,7 @@ SIGNATURES = {
     "sph3d_last_error": (ctypes.c_char_p, []),
     "sph3d_build_info": (ctypes.c_char_p, []),
     "sph3d_build_sphere_neighbor": (_I, [_I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
+    "sph3d_build_sphere_neighbor_fixed": (_I, [_I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "sph3d_build_cube_neighbor": (_I, [_I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P]),
     "sph3d_spherical_kernel": (_I, [_I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
     "sph3d_spherical_kernel_ocml": (_I, [_I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),

@@ -72,7 +72,7 @@ __device__ __forceinline__ void stage_cloud(const float* __restrict__ dbi, int c
 // correctly rounded sqrtf and two scattered stores on the whole wave (~40 such strips per query at S3DIS level 0).
 template <int CPW, bool MULTI, bool DEFER>
 __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
-    int B, int N, int M, int K, float radius0, int chunkN, int groups,
+    int B, int N, int M, int K, float radius0, int chunkN, int groups, int fixed,
     const float* __restrict__ database, const float* __restrict__ query,
     int* __restrict__ nnIndex, int* __restrict__ nnCount, float* __restrict__ nnDist)
 {
@@ -111,6 +111,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
             passes[c] = 0;
             qx[c] = qy[c] = qz[c] = 0.0f;
             thr[c] = 0.0f;
+            if (fixed) r[c] = radius0;          // fixed-radius mode: nothing is carried from cloud to cloud
             if (has[c]) {
                 qx[c] = qi[j[c] * 3];
                 qy[c] = qi[j[c] * 3 + 1];
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
                         has[c] = j[c] < M;
                         s[c] = 0;
                         passes[c] = 0;
+                        if (fixed) r[c] = radius0;          // fixed-radius mode: every query starts from the nominal radius
                         if (has[c]) {
                             qx[c] = qi[j[c] * 3];
                             qy[c] = qi[j[c] * 3 + 1];
@@ -292,7 +294,7 @@ static size_t hits_bytes(int CPW, int K)
 template <int CPW, bool MULTI, bool DEFER>
 static int launch_sphere(int B, int N, int M, int K, float radius, int chunkN,
                          const float* database, const float* query,
-                         int* nn_index, int* nn_count, float* nn_dist, hipStream_t stream)
+                         int* nn_index, int* nn_count, float* nn_dist, hipStream_t stream, int fixed)
 {
     const int nb = B < kRefGrid ? B : kRefGrid;
     const int nt = M < kRefBlock ? M : kRefBlock;
@@ -305,7 +307,7 @@ static int launch_sphere(int B, int N, int M, int K, float radius, int chunkN,
         if (rc) return rc;
     }
     hipLaunchKernelGGL(kern, dim3(nb * groups), dim3(kWavesPerWG * 64), lds, stream,
-                       B, N, M, K, radius, chunkN, groups, database, query, nn_index, nn_count, nn_dist);
+                       B, N, M, K, radius, chunkN, groups, fixed, database, query, nn_index, nn_count, nn_dist);
     return check_launch("sph3d_build_sphere_neighbor");
 }
 
@@ -313,10 +315,10 @@ static int launch_sphere(int B, int N, int M, int K, float radius, int chunkN,
 
 using namespace sph3d;
 
-extern "C" int sph3d_build_sphere_neighbor(int B, int N, int M, int nn_sample, float radius,
-                                           const float* database, const float* query,
-                                           int* nn_index, int* nn_count, float* nn_dist,
-                                           sph3d_stream_t stream)
+static int sphere_neighbor(int fixed, int B, int N, int M, int nn_sample, float radius,
+                           const float* database, const float* query,
+                           int* nn_index, int* nn_count, float* nn_dist,
+                           sph3d_stream_t stream)
 {
     SPH3D_REQUIRE(radius > 0, "Range search requires radius>0, got %g", (double)radius);          // tf_nnquery.cpp:60
     SPH3D_REQUIRE(nn_sample > 0, "BuildSphereNeighbor requires nn_sample>0, got %d", nn_sample);  // :63
@@ -338,13 +340,29 @@ extern "C" int sph3d_build_sphere_neighbor(int B, int N, int M, int nn_sample, f
         chunkN = maxChunk;
     }
 #define SPH3D_NN(CP, MU)                                                                                          \
-    return hb ? launch_sphere<CP, MU, true>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st) \
-              : launch_sphere<CP, MU, false>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st)
+    return hb ? launch_sphere<CP, MU, true>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st, fixed) \
+              : launch_sphere<CP, MU, false>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st, fixed)
     if (multi) { SPH3D_NN(1, true); }
     if (cpw == 4) { SPH3D_NN(4, false); }
     if (cpw == 2) { SPH3D_NN(2, false); }
     SPH3D_NN(1, false);
 #undef SPH3D_NN
+}
+
+extern "C" int sph3d_build_sphere_neighbor(int B, int N, int M, int nn_sample, float radius,
+                                           const float* database, const float* query,
+                                           int* nn_index, int* nn_count, float* nn_dist,
+                                           sph3d_stream_t stream)
+{
+    return sphere_neighbor(0, B, N, M, nn_sample, radius, database, query, nn_index, nn_count, nn_dist, stream);
+}
+
+extern "C" int sph3d_build_sphere_neighbor_fixed(int B, int N, int M, int nn_sample, float radius,
+                                                 const float* database, const float* query,
+                                                 int* nn_index, int* nn_count, float* nn_dist,
+                                                 sph3d_stream_t stream)
+{
+    return sphere_neighbor(1, B, N, M, nn_sample, radius, database, query, nn_index, nn_count, nn_dist, stream);
 }
 
 extern "C" int sph3d_build_cube_neighbor(int B, int N, int M, int grid_size, int nn_sample, float length,

@@ -10,6 +10,18 @@ import torch
 
 from . import _lib
 
+_radius_mode = "compat"
+
+
+def set_radius_mode(mode):
+    """"compat" (default): the reference's semantics, bit-exact — the radius a reference thread grew is carried to the next
+    query of its chain (tf_nnquery_gpu.cu:59).  "fixed": every query is searched with the nominal radius (growth only until
+    it has a neighbour) — a labelled deviation for clouds far larger than the reference's 8192-point blocks."""
+    global _radius_mode
+    if mode not in ("compat", "fixed"):
+        raise ValueError("radius mode must be 'compat' or 'fixed'")
+    _radius_mode = mode
+
 
 def _build_sphere_neighbor_impl(database: torch.Tensor, query: torch.Tensor, radius: float,
                            nn_sample: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -25,7 +37,9 @@ def _build_sphere_neighbor_impl(database: torch.Tensor, query: torch.Tensor, rad
     nn_index = torch.empty((B, M, nn_sample), dtype=torch.int32, device=database.device)
     nn_count = torch.empty((B, M), dtype=torch.int32, device=database.device)
     nn_dist = torch.empty((B, M, nn_sample), dtype=torch.float32, device=database.device)
-    _lib.check(_lib.lib().sph3d_build_sphere_neighbor(
+    l = _lib.lib()
+    fn = l.sph3d_build_sphere_neighbor_fixed if _radius_mode == "fixed" else l.sph3d_build_sphere_neighbor
+    _lib.check(fn(
         B, N, M, nn_sample, radius, _lib.ptr(database), _lib.ptr(query),
         _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(nn_dist), _lib.stream_ptr()))
     return nn_index, nn_count, nn_dist

@@ -164,3 +164,33 @@ def test_scannet_65536_level0_feature_ops(dev):
     gu[:, :2048] = rng.randn(1, 2048, C)
     up.backward(torch.from_numpy(gu).to(dev))
     np.testing.assert_allclose(_n(cg.grad), oracle.mean_interpolate_grad(cf, gu[:, :2048], uio, uco), **TOL)
+
+
+def test_scannet_65536_fixed_radius_mode(dev):
+    """config 5 in the labelled FIXED-radius mode (not reference semantics: every query searched at the nominal radius):
+    bit-exact against the oracle's fixed-radius restatement on two slices, far fewer saturated rows than compat mode, and
+    the level-0 conv / bins run on that graph."""
+    N, K, r = 65536, 64, 0.1
+    xyz = synth.s3dis_batch(77, 1, N, extent=(6.0, 6.0, 3.0))[0]
+    xt = torch.from_numpy(xyz).to(dev)
+    tf_nnquery.set_radius_mode("fixed")
+    try:
+        idx, cnt, dst = tf_nnquery.build_sphere_neighbor(xt, xt, r, None, K)
+    finally:
+        tf_nnquery.set_radius_mode("compat")
+    idx_n, cnt_n = _graph_properties(idx, cnt, K, N)
+    ic, cc, _dc = tf_nnquery.build_sphere_neighbor(xt, xt, r, None, K)
+    assert (cnt_n == K).mean() < 0.5 * float((cc == K).float().mean())          # the chain no longer inflates the radius
+    assert torch.equal(idx[:, :1024], ic[:, :1024])                              # chain position 0: same search
+    for lo in (0, 40000):
+        io, co, do = oracle.build_sphere_neighbor(xyz, xyz[:, lo:lo + 1024], r, None, K, fixed=True)
+        np.testing.assert_array_equal(idx_n[:, lo:lo + 1024], io)
+        np.testing.assert_array_equal(cnt_n[:, lo:lo + 1024], co)
+        np.testing.assert_array_equal(_n(dst)[:, lo:lo + 1024].view(np.int32), do.view(np.int32))
+    filt = tf_buildkernel.spherical_kernel(xt, xt, idx, cnt, dst, r, [8, 2, 2])
+    x = torch.randn(1, N, 64, device=dev)
+    w = torch.randn(33, 64, 2, device=dev)
+    out = tf_conv3d.depthwise_conv3d(x, w, idx, cnt, filt)
+    io, co, do = oracle.build_sphere_neighbor(xyz, xyz[:, :512], r, None, K, fixed=True)
+    fo = oracle.spherical_kernel(xyz, xyz[:, :512], io, co, do, r, [8, 2, 2])
+    np.testing.assert_allclose(_n(out)[:, :512], oracle.depthwise_conv3d(_n(x), _n(w), io, co, fo), **TOL)

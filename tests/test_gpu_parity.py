@@ -116,6 +116,23 @@ def test_bins_ocml_mode_equal_reference_build_full_batch(dev):
     _assert_mismatches_on_boundaries(_n(xyz), _n(xyz), _n(idx), _n(fs), _n(rf), [8, 2, 2])
 
 
+@pytest.mark.parametrize("case", NN_CASES, ids=lambda c: "%s-B%d-N%d-M%s-r%g-K%d" % c)
+def test_sphere_neighbor_fixed_radius_mode(dev, case):
+    """the labelled non-reference mode (radius reset for every query) against the oracle's restatement of it"""
+    kind, B, N, M, radius, K = case
+    db = _clouds(kind, B, N, seed=5)
+    q = db if M is None else _clouds("uniform", B, M, seed=9) * db.max()
+    idx_o, cnt_o, dst_o = oracle.build_sphere_neighbor(db, q, radius, None, K, fixed=True)
+    tf_nnquery.set_radius_mode("fixed")
+    try:
+        idx, cnt, dst = tf_nnquery.build_sphere_neighbor(_t(db, dev), _t(q, dev), radius, None, K)
+    finally:
+        tf_nnquery.set_radius_mode("compat")
+    np.testing.assert_array_equal(_n(cnt), cnt_o)
+    np.testing.assert_array_equal(_n(idx), idx_o)
+    np.testing.assert_array_equal(_n(dst).view(np.int32), dst_o.view(np.int32))
+
+
 @pytest.mark.parametrize("B,N,M,K,L,G", [(2, 300, 100, 8, 0.3, 3), (1, 1000, 1000, 20, 0.1, 4), (3, 77, 5, 70, 0.9, 2)])
 def test_cube_neighbor_bitexact(dev, B, N, M, K, L, G):
     db = _clouds("uniform", B, N, seed=2)

@@ -254,3 +254,27 @@ def test_arg_validation():
             oracle.spherical_kernel(db, db, idx, cnt, dst, 0.1, bad)
     with pytest.raises(ValueError):
         oracle.farthest_point_sample(0, db)
+
+
+def test_fixed_radius_variant_is_an_independent_search_per_query():
+    """oracle_build_sphere_neighbor_fixed (the labelled non-reference mode): every query = brute force at the nominal
+    radius, growing by 0.05 only while it has no neighbour; identical to compat mode at chain position 0."""
+    rng = np.random.RandomState(4)
+    B, N, M, K, r = 2, 400, 1500, 8, 0.08
+    db = rng.rand(B, N, 3).astype(np.float32)
+    q = rng.rand(B, M, 3).astype(np.float32)
+    idx, cnt, dst = oracle.build_sphere_neighbor(db, q, r, None, K, fixed=True)
+    ic, cc, dc = oracle.build_sphere_neighbor(db, q, r, None, K)
+    np.testing.assert_array_equal(idx[:, :1024], ic[:, :1024])
+    assert cc[:, 1024:].mean() > cnt[:, 1024:].mean()
+    for b in range(B):
+        for m in range(0, M, 37):
+            rad = np.float32(r)
+            while True:
+                d = np.sqrt(((db[b] - q[b, m]) ** 2).astype(np.float32).sum(1, dtype=np.float32)).astype(np.float32)
+                hit = np.nonzero((d < rad) & (np.abs(d - rad).astype(np.float64) > 1e-6))[0]
+                if len(hit):
+                    break
+                rad = np.float32(np.float64(rad) + 0.05)
+            assert cnt[b, m] == min(len(hit), K)
+            assert idx[b, m, :cnt[b, m]].tolist() == hit[:K].tolist()
