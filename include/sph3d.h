@@ -78,6 +78,16 @@ int sph3d_build_cube_neighbor(int B, int N, int M, int grid_size, int nn_sample,
                               int* nn_index, int* nn_count,
                               sph3d_stream_t stream);
 
+/* Fused graph construction of one level: neighbour search + spherical-kernel bins in ONE kernel, and — when
+ * transpose_workspace is given (sph3d_graph_transpose_workspace bytes) — the counting pass of the transposed graph as
+ * well (finish it with sph3d_graph_transpose_finish).  Outputs equal, bit for bit, sph3d_build_sphere_neighbor followed by
+ * sph3d_spherical_kernel(n, p, q, radius) on the same database / query; shapes whose per-query hit lists do not fit LDS
+ * run those kernels one after the other. */
+int sph3d_build_sphere_graph(int B, int N, int M, int nn_sample, float radius, int n, int p, int q,
+                             const float* database, const float* query,
+                             int* nn_index, int* nn_count, float* nn_dist, int* filt_index,
+                             void* transpose_workspace, size_t transpose_workspace_bytes, sph3d_stream_t stream);
+
 /* ---- buildkernel --------------------------------------------------------
  * replaces sphericalKernelLauncher (tf_ops/buildkernel/tf_buildkernel_gpu.cu:83-89;
  * kernel build_spherical_kernel :20-79; op SphericalKernel tf_buildkernel.cpp:35-99).
@@ -138,6 +148,15 @@ int sph3d_graph_transpose(int B, int N, int M, int K, int F,
                           int* offsets, int* ent_key, float* ent_scale,
                           int* active_bins /* [F+1] or NULL: count, then the ascending list of the bins that occur */,
                           void* workspace, size_t workspace_bytes, sph3d_stream_t stream);
+/* The two phases of sph3d_graph_transpose on one workspace: segment counts (also produced by sph3d_build_sphere_graph), then
+ * scan + fill. */
+int sph3d_graph_transpose_count(int B, int N, int M, int K, int F, const int* nn_index, const int* nn_count,
+                                const int* bin_index, int want_active, void* workspace, size_t workspace_bytes,
+                                sph3d_stream_t stream);
+int sph3d_graph_transpose_finish(int B, int N, int M, int K, int F,
+                                 const int* nn_index, const int* nn_count, const int* bin_index,
+                                 const float* weight, int* offsets, int* ent_key, float* ent_scale, int* active_bins,
+                                 void* workspace, size_t workspace_bytes, sph3d_stream_t stream);
 /* conv gradients from a prebuilt transposed graph: both gradients in one pass, no float atomics
  * (grad_input gathered in registers; grad_filter accumulated in per-lane registers by persistent workgroups
  * that sweep the clouds of their XCD, one partial table per workgroup written to `workspace` =

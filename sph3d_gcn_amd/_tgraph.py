@@ -41,10 +41,11 @@ def source_order(nn_index):
     return None if hit is None else hit[0]
 
 
-def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1):
+def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1, counted_workspace=None):
     """-> (offsets[B*(n_src*F+1)] i32, ent_key[B*M*K] i32, ent_scale[B*M*K] f32, active_bins[F+1] i32 | None) on
     nn_index's device; F = num_bins (the filter's bin count when bin_index is given, else 1); active_bins (count, then
-    the bins that occur) is produced for binned graphs only"""
+    the bins that occur) is produced for binned graphs only.  counted_workspace: a transpose workspace whose counting
+    phase has already run (tf_nnquery.build_sphere_graph did it inside the neighbour search): only scan + fill remain"""
     F = int(num_bins) if bin_index is not None else 1
     key = (_ident(nn_index), _ident(nn_count), _ident(bin_index), _ident(weight), int(n_src), F, tuple(nn_index.shape))
     cur = torch.cuda.current_stream()
@@ -66,10 +67,16 @@ def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1
     active = torch.empty((F + 1,), dtype=torch.int32, device=dev) if bin_index is not None else None
     l = _lib.lib()
     wsb = l.sph3d_graph_transpose_workspace(B, n_src, M, K, F)
-    ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
-    _lib.check(l.sph3d_graph_transpose(B, n_src, M, K, F, _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(bin_index),
-                                       _lib.ptr(weight), _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale),
-                                       _lib.ptr(active), _lib.ptr(ws), wsb, _lib.stream_ptr()))
+    if counted_workspace is not None:
+        _lib.check(l.sph3d_graph_transpose_finish(B, n_src, M, K, F, _lib.ptr(nn_index), _lib.ptr(nn_count),
+                                                  _lib.ptr(bin_index), _lib.ptr(weight), _lib.ptr(offsets), _lib.ptr(ent_key),
+                                                  _lib.ptr(ent_scale), _lib.ptr(active), _lib.ptr(counted_workspace), wsb,
+                                                  _lib.stream_ptr()))
+    else:
+        ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
+        _lib.check(l.sph3d_graph_transpose(B, n_src, M, K, F, _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(bin_index),
+                                           _lib.ptr(weight), _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale),
+                                           _lib.ptr(active), _lib.ptr(ws), wsb, _lib.stream_ptr()))
     out = (offsets, ent_key, ent_scale, active)
     ev = torch.cuda.Event()
     ev.record(cur)

@@ -180,42 +180,88 @@ extern "C" size_t sph3d_graph_transpose_workspace(int B, int N, int M, int K, in
     return sizeof(int) * ((size_t)B * L + (size_t)F + (size_t)B * ((L + kChunk - 1) / kChunk) + (size_t)B * M * K);
 }
 
-extern "C" int sph3d_graph_transpose(int B, int N, int M, int K, int F,
-                                     const int* nn_index, const int* nn_count, const int* bin_index,
-                                     const float* weight, int* offsets, int* ent_key, float* ent_scale, int* active_bins,
-                                     void* workspace, size_t workspace_bytes, sph3d_stream_t stream)
+// layout of the workspace
+struct TgWs {
+    int* deg; int* bin_used; int* sums; int* slot_pos; int L; int chunks;
+};
+static TgWs tg_ws(void* workspace, int B, int N, int M, int K, int F)
+{
+    TgWs w;
+    w.L = N * F;
+    w.chunks = (w.L + kChunk - 1) / kChunk;
+    w.deg = (int*)workspace;
+    w.bin_used = w.deg + (size_t)B * w.L;                               // [F] flags, zeroed with the counters
+    w.sums = w.bin_used + F;
+    w.slot_pos = w.sums + (size_t)B * w.chunks;                         // [B*M*K] position of every edge inside its segment
+    return w;
+}
+
+static int tg_dims_ok(int B, int N, int M, int K, int F, const void* bin_index, const void* workspace, size_t workspace_bytes)
 {
     SPH3D_REQUIRE(B >= 0 && N > 0 && M >= 0 && K > 0, "graph_transpose: bad dims B=%d N=%d M=%d K=%d", B, N, M, K);
     SPH3D_REQUIRE(F >= 1 && (bin_index != nullptr || F == 1), "graph_transpose: F=%d needs a bin_index", F);
     SPH3D_REQUIRE((long long)N * F < (1LL << 31), "graph_transpose: N*F overflows int32");
     SPH3D_REQUIRE((long long)B * M * K < (1LL << 31), "graph_transpose: B*M*K overflows int32");
-    if (B == 0) return SPH3D_OK;
     const size_t need = sph3d_graph_transpose_workspace(B, N, M, K, F);
-    if (workspace == nullptr || workspace_bytes < need) {
+    if (B > 0 && (workspace == nullptr || workspace_bytes < need)) {
         set_error("graph_transpose: workspace %zu B < required %zu B", workspace_bytes, need);
         return SPH3D_EWORKSPACE;
     }
+    return SPH3D_OK;
+}
+
+// phase 1: segment counts (+ the position of every edge in its segment, + which bins occur).  sph3d_build_sphere_graph
+// produces the same three arrays from inside the neighbour search.
+extern "C" int sph3d_graph_transpose_count(int B, int N, int M, int K, int F, const int* nn_index, const int* nn_count,
+                                           const int* bin_index, int want_active, void* workspace, size_t workspace_bytes,
+                                           sph3d_stream_t stream)
+{
+    int rc = tg_dims_ok(B, N, M, K, F, bin_index, workspace, workspace_bytes);
+    if (rc || B == 0) return rc;
     hipStream_t st = as_stream(stream);
-    int* deg = (int*)workspace;
-    int rc = check_hip(hipMemsetAsync(deg, 0, sizeof(int) * ((size_t)B * N * F + F), st), "graph_transpose: memset");
+    const TgWs w = tg_ws(workspace, B, N, M, K, F);
+    rc = check_hip(hipMemsetAsync(w.deg, 0, sizeof(int) * ((size_t)B * w.L + F), st), "graph_transpose: memset");
     if (rc) return rc;
     const long long total = (long long)B * M * K;
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    const int L = N * F;
-    const int chunks = (L + kChunk - 1) / kChunk;
-    int* bin_used = deg + (size_t)B * L;                            // [F] flags, zeroed with the counters
-    int* sums = bin_used + F;
-    int* slot_pos = sums + (size_t)B * chunks;                      // [B*M*K] position of every edge inside its segment
     if (total > 0)
-        hipLaunchKernelGGL(tg_count, dim3((unsigned)blocks), dim3(256), 0, st, B, N, M, K, F, nn_index, nn_count, bin_index, deg,
-                           slot_pos, active_bins ? bin_used : nullptr);
-    if (active_bins) hipLaunchKernelGGL(tg_active_bins, dim3(1), dim3(256), 0, st, F, bin_used, active_bins);
-    hipLaunchKernelGGL(tg_chunk_sums, dim3(B * chunks), dim3(256), 0, st, L, chunks, deg, sums);
-    hipLaunchKernelGGL(tg_scan_sums, dim3(B), dim3(256), 0, st, chunks, M * K, sums);
-    hipLaunchKernelGGL(tg_apply, dim3(B * chunks), dim3(256), 0, st, L, chunks, deg, sums, offsets);
+        hipLaunchKernelGGL(tg_count, dim3((unsigned)blocks), dim3(256), 0, st, B, N, M, K, F, nn_index, nn_count, bin_index, w.deg,
+                           w.slot_pos, want_active ? w.bin_used : nullptr);
+    return check_launch("sph3d_graph_transpose_count");
+}
+
+// phase 2: scan of the counts -> offsets, then the fill pass (no atomics: every edge knows its position)
+extern "C" int sph3d_graph_transpose_finish(int B, int N, int M, int K, int F,
+                                            const int* nn_index, const int* nn_count, const int* bin_index,
+                                            const float* weight, int* offsets, int* ent_key, float* ent_scale, int* active_bins,
+                                            void* workspace, size_t workspace_bytes, sph3d_stream_t stream)
+{
+    int rc = tg_dims_ok(B, N, M, K, F, bin_index, workspace, workspace_bytes);
+    if (rc || B == 0) return rc;
+    hipStream_t st = as_stream(stream);
+    const TgWs w = tg_ws(workspace, B, N, M, K, F);
+    const long long total = (long long)B * M * K;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (active_bins) hipLaunchKernelGGL(tg_active_bins, dim3(1), dim3(256), 0, st, F, w.bin_used, active_bins);
+    hipLaunchKernelGGL(tg_chunk_sums, dim3(B * w.chunks), dim3(256), 0, st, w.L, w.chunks, w.deg, w.sums);
+    hipLaunchKernelGGL(tg_scan_sums, dim3(B), dim3(256), 0, st, w.chunks, M * K, w.sums);
+    hipLaunchKernelGGL(tg_apply, dim3(B * w.chunks), dim3(256), 0, st, w.L, w.chunks, w.deg, w.sums, offsets);
     if (total > 0)
         hipLaunchKernelGGL(tg_fill, dim3((unsigned)blocks), dim3(256), 0, st, B, N, M, K, F, nn_index, nn_count, bin_index,
-                           weight, offsets, slot_pos, ent_key, ent_scale);
+                           weight, offsets, w.slot_pos, ent_key, ent_scale);
     return check_launch("sph3d_graph_transpose");
+}
+
+extern "C" int sph3d_graph_transpose(int B, int N, int M, int K, int F,
+                                     const int* nn_index, const int* nn_count, const int* bin_index,
+                                     const float* weight, int* offsets, int* ent_key, float* ent_scale, int* active_bins,
+                                     void* workspace, size_t workspace_bytes, sph3d_stream_t stream)
+{
+    int rc = sph3d_graph_transpose_count(B, N, M, K, F, nn_index, nn_count, bin_index, active_bins != nullptr, workspace,
+                                         workspace_bytes, stream);
+    if (rc) return rc;
+    return sph3d_graph_transpose_finish(B, N, M, K, F, nn_index, nn_count, bin_index, weight, offsets, ent_key, ent_scale,
+                                        active_bins, workspace, workspace_bytes, stream);
 }

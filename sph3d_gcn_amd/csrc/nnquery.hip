@@ -18,6 +18,7 @@
 //     bit-identical decisions.
 //   * -ffp-contract=off: d2 = (dx*dx + dy*dy) + dz*dz must round exactly like the oracle.
 #include "common.hpp"
+#include "sphere_bin.hpp"
 
 namespace sph3d {
 
@@ -70,9 +71,22 @@ __device__ __forceinline__ void stage_cloud(const float* __restrict__ dbi, int c
 // the finished query (indices, sqrt(sqrt(d2)), zero fill) are produced by ONE coalesced pass over its <= K slots.  The
 // first version wrote nn_index / nn_dist from inside the strip loop: every strip with at least one hit ran two
 // correctly rounded sqrtf and two scattered stores on the whole wave (~40 such strips per query at S3DIS level 0).
-template <int CPW, bool MULTI, bool DEFER>
+// FUSE (sph3d_build_sphere_graph): the output pass of a finished query also computes the spherical-kernel bin of every
+// neighbour (the operands dx, dy, dz, sqrt-distance are in registers there) and, when a transposed graph will be
+// needed, counts the edge into its (source point, bin) segment — the atomic's return value is the edge's position in
+// the segment (graph.hip).  Replaces one launch + one pass over [B,M,K] for the bins and one for the segment counts.
+struct GraphFuse {
+    int n, p, q, F;          // spherical kernel sizes, F = n*p*q + 1
+    float radius;            // nominal radius of the binning (not the chain's grown radius)
+    int* filt;               // [B,M,K] bin ids
+    int* deg;                // [B*N*F] segment counters (zeroed by the caller) or nullptr
+    int* slotPos;            // [B*M*K]
+    int* binUsed;            // [F]
+};
+
+template <int CPW, bool MULTI, bool DEFER, bool FUSE>
 __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
-    int B, int N, int M, int K, float radius0, int chunkN, int groups, int fixed,
+    int B, int N, int M, int K, float radius0, int chunkN, int groups, int fixed, GraphFuse fx,
     const float* __restrict__ database, const float* __restrict__ query,
     int* __restrict__ nnIndex, int* __restrict__ nnCount, float* __restrict__ nnDist)
 {
@@ -203,7 +217,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
                             // the query's K output slots in one coalesced pass: distance recomputed from the same operands
                             const int* h = lhits + (wave * CPW + c) * K;
                             for (int slot = lane; slot < K; slot += 64) {
-                                int id = 0;
+                                int id = 0, bin = 0;
                                 float dist = 0.0f;
                                 if (slot < cnt) {
                                     id = h[slot];
@@ -212,9 +226,17 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
                                     const float dz = dbi[(size_t)id * 3 + 2] - qz[c];
                                     const float d2 = (dx * dx + dy * dy) + dz * dz;   // tf_nnquery_gpu.cu:45-46
                                     dist = sqrtf(sqrtf(d2));                          // :47 then :54 — sqrt of the distance
+                                    if (FUSE) {
+                                        bin = sphere_bin<false>(dx, dy, dz, dist, fx.radius, fx.n, fx.p, fx.q);
+                                        if (fx.deg != nullptr) {
+                                            fx.slotPos[row * K + slot] = atomicAdd(&fx.deg[((size_t)i * N + id) * fx.F + bin], 1);
+                                            fx.binUsed[bin] = 1;          // benign race: every writer stores 1
+                                        }
+                                    }
                                 }
                                 nnIndex[row * K + slot] = id;                          // unused slots read 0
                                 nnDist[row * K + slot] = dist;
+                                if (FUSE) fx.filt[row * K + slot] = bin;
                             }
                         } else {
                             for (int slot = cnt + lane; slot < K; slot += 64) {   // unused slots read 0
@@ -294,20 +316,34 @@ static size_t hits_bytes(int CPW, int K)
 template <int CPW, bool MULTI, bool DEFER>
 static int launch_sphere(int B, int N, int M, int K, float radius, int chunkN,
                          const float* database, const float* query,
-                         int* nn_index, int* nn_count, float* nn_dist, hipStream_t stream, int fixed)
+                         int* nn_index, int* nn_count, float* nn_dist, hipStream_t stream, int fixed,
+                         const GraphFuse* fuse = nullptr)
 {
     const int nb = B < kRefGrid ? B : kRefGrid;
     const int nt = M < kRefBlock ? M : kRefBlock;
     const int groups = (nt + kWavesPerWG * CPW - 1) / (kWavesPerWG * CPW);
     const size_t lds = (size_t)3 * chunkN * sizeof(float) + (DEFER ? hits_bytes(CPW, K) : 0);
-    auto kern = nnquery_sphere_kernel<CPW, MULTI, DEFER>;
+    if constexpr (DEFER) {
+        if (fuse != nullptr) {
+            auto kernf = nnquery_sphere_kernel<CPW, MULTI, DEFER, true>;
+            if (lds > 64 * 1024) {
+                int rc = check_hip(hipFuncSetAttribute((const void*)kernf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                                   "nnquery: hipFuncSetAttribute");
+                if (rc) return rc;
+            }
+            hipLaunchKernelGGL(kernf, dim3(nb * groups), dim3(kWavesPerWG * 64), lds, stream,
+                               B, N, M, K, radius, chunkN, groups, fixed, *fuse, database, query, nn_index, nn_count, nn_dist);
+            return check_launch("sph3d_build_sphere_graph");
+        }
+    }
+    auto kern = nnquery_sphere_kernel<CPW, MULTI, DEFER, false>;
     if (lds > 64 * 1024) {
         int rc = check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                            "nnquery: hipFuncSetAttribute");
         if (rc) return rc;
     }
     hipLaunchKernelGGL(kern, dim3(nb * groups), dim3(kWavesPerWG * 64), lds, stream,
-                       B, N, M, K, radius, chunkN, groups, fixed, database, query, nn_index, nn_count, nn_dist);
+                       B, N, M, K, radius, chunkN, groups, fixed, GraphFuse{}, database, query, nn_index, nn_count, nn_dist);
     return check_launch("sph3d_build_sphere_neighbor");
 }
 
@@ -318,8 +354,9 @@ using namespace sph3d;
 static int sphere_neighbor(int fixed, int B, int N, int M, int nn_sample, float radius,
                            const float* database, const float* query,
                            int* nn_index, int* nn_count, float* nn_dist,
-                           sph3d_stream_t stream)
+                           sph3d_stream_t stream, const GraphFuse* fuse = nullptr, bool* fused = nullptr)
 {
+    if (fused) *fused = false;
     SPH3D_REQUIRE(radius > 0, "Range search requires radius>0, got %g", (double)radius);          // tf_nnquery.cpp:60
     SPH3D_REQUIRE(nn_sample > 0, "BuildSphereNeighbor requires nn_sample>0, got %d", nn_sample);  // :63
     SPH3D_REQUIRE(B >= 0 && N > 0 && M >= 0, "BuildSphereNeighbor: bad dims B=%d N=%d M=%d", B, N, M);
@@ -339,8 +376,9 @@ static int sphere_neighbor(int fixed, int B, int N, int M, int nn_sample, float 
         if (maxChunk > kMaxChunk) maxChunk = kMaxChunk;
         chunkN = maxChunk;
     }
+    if (fused) *fused = (fuse != nullptr) && hb != 0;       // the bins come from the deferred output pass
 #define SPH3D_NN(CP, MU)                                                                                          \
-    return hb ? launch_sphere<CP, MU, true>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st, fixed) \
+    return hb ? launch_sphere<CP, MU, true>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st, fixed, fuse) \
               : launch_sphere<CP, MU, false>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st, fixed)
     if (multi) { SPH3D_NN(1, true); }
     if (cpw == 4) { SPH3D_NN(4, false); }
@@ -363,6 +401,55 @@ extern "C" int sph3d_build_sphere_neighbor_fixed(int B, int N, int M, int nn_sam
                                                  sph3d_stream_t stream)
 {
     return sphere_neighbor(1, B, N, M, nn_sample, radius, database, query, nn_index, nn_count, nn_dist, stream);
+}
+
+// Fused graph construction of one level: neighbour search + spherical-kernel bins (+ the segment counts of
+// the transposed graph) in ONE kernel.  Same outputs, bit for bit, as sph3d_build_sphere_neighbor followed by
+// sph3d_spherical_kernel with the same database / query (and sph3d_graph_transpose's counting pass).
+extern "C" int sph3d_spherical_kernel(int B, int N, int M, int K, int n, int p, int q, float radius,
+                                      const float* database, const float* query,
+                                      const int* nn_index, const int* nn_count, const float* nn_dist,
+                                      int* filt_index, sph3d_stream_t stream);
+extern "C" int sph3d_graph_transpose_count(int B, int N, int M, int K, int F, const int* nn_index, const int* nn_count,
+                                           const int* bin_index, int want_active, void* workspace, size_t workspace_bytes,
+                                           sph3d_stream_t stream);
+
+extern "C" int sph3d_build_sphere_graph(int B, int N, int M, int nn_sample, float radius, int n, int p, int q,
+                                        const float* database, const float* query,
+                                        int* nn_index, int* nn_count, float* nn_dist, int* filt_index,
+                                        void* transpose_workspace, size_t transpose_workspace_bytes, sph3d_stream_t stream)
+{
+    SPH3D_REQUIRE(n > 2 && n % 2 == 0, "Need n_>2 and n_%%2==0, got %d", n);               // tf_buildkernel.cpp:43
+    SPH3D_REQUIRE(p > 0 && p % 2 == 0, "Need p_>0 and p_%%2==0, got %d", p);               // :46
+    SPH3D_REQUIRE(q > 0, "Need q_>0, got %d", q);                                          // :49
+    const int F = n * p * q + 1;
+    GraphFuse fx{};
+    fx.n = n; fx.p = p; fx.q = q; fx.F = F;
+    fx.radius = radius;
+    fx.filt = filt_index;
+    if (transpose_workspace != nullptr) {
+        const size_t need = sph3d_graph_transpose_workspace(B, N, M, nn_sample, F);
+        if (transpose_workspace_bytes < need) {
+            set_error("build_sphere_graph: transpose workspace %zu B < required %zu B", transpose_workspace_bytes, need);
+            return SPH3D_EWORKSPACE;
+        }
+        // layout of graph.hip: counters [B*N*F], bin flags [F], chunk sums, slot positions [B*M*K]
+        const size_t L = (size_t)N * F;
+        const size_t chunks = (L + 2047) / 2048;
+        fx.deg = (int*)transpose_workspace;
+        fx.binUsed = fx.deg + (size_t)B * L;
+        fx.slotPos = fx.binUsed + F + (size_t)B * chunks;
+        int rc = check_hip(hipMemsetAsync(fx.deg, 0, sizeof(int) * ((size_t)B * L + F), as_stream(stream)), "build_sphere_graph: memset");
+        if (rc) return rc;
+    }
+    bool fused = false;
+    int rc = sphere_neighbor(0, B, N, M, nn_sample, radius, database, query, nn_index, nn_count, nn_dist, stream, &fx, &fused);
+    if (rc || fused) return rc;
+    // shapes whose hit lists do not fit LDS: the same results from the separate kernels
+    rc = sph3d_spherical_kernel(B, N, M, nn_sample, n, p, q, radius, database, query, nn_index, nn_count, nn_dist, filt_index, stream);
+    if (rc || transpose_workspace == nullptr) return rc;
+    return sph3d_graph_transpose_count(B, N, M, nn_sample, F, nn_index, nn_count, filt_index, 1, transpose_workspace,
+                                       transpose_workspace_bytes, stream);
 }
 
 extern "C" int sph3d_build_cube_neighbor(int B, int N, int M, int grid_size, int nn_sample, float length,

@@ -158,8 +158,8 @@ class GraphPlan:
     def _make_enc(self, l):
         c = self.config
         xyz = self.xyz_layers[l]
-        idx, cnt, dst = s3g_util.neighbor_fn(xyz, xyz, radius=c.radius[l], nnsample=c.nn_uplimit[l])      # util.py:29
-        filt = s3g_util.spherical_kernel(xyz, xyz, idx, cnt, dst, c.radius[l], kernel=c.kernel)
+        # util.py:29 + models/SPH3D_s3dis.py:57: neighbour graph and bins of one point set, one fused kernel on the GPU
+        idx, cnt, dst, filt = s3g_util.build_intra_graph(xyz, c.radius[l], c.nn_uplimit[l], c.kernel)
         return dict(intra_idx=idx, intra_cnt=cnt, filt_idx=filt)
 
     def _make_pool(self, l, g):
@@ -171,9 +171,9 @@ class GraphPlan:
         L = len(c.radius)
         radius, uplimit = c.radius[L - 1 - l], c.nn_uplimit[L - 1 - l]
         xyz_c, xyz_unpool = self.xyz_layers[L - l], self.xyz_layers[L - 1 - l]     # = reversed(xyz_layers)[l], [l + 1]
-        intra_idx, intra_cnt, intra_dst, inter_idx, inter_cnt, inter_dst = s3g_util.build_graph_deconv(
-            xyz_c, xyz_unpool, radius, uplimit)
-        filt_idx = s3g_util.spherical_kernel(xyz_c, xyz_c, intra_idx, intra_cnt, intra_dst, radius, kernel=c.kernel)
+        # build_graph_deconv (util.py:52-58) + spherical_kernel: the intra half fused, the inter search as is
+        intra_idx, intra_cnt, intra_dst, filt_idx = s3g_util.build_intra_graph(xyz_c, radius, uplimit, c.kernel)
+        inter_idx, inter_cnt, inter_dst = s3g_util.neighbor_fn(xyz_c, xyz_unpool, radius=radius, nnsample=uplimit)
         return dict(intra_idx=intra_idx, intra_cnt=intra_cnt, filt_idx=filt_idx, inter_idx=inter_idx,
                     inter_cnt=inter_cnt, inter_dst=inter_dst)
 

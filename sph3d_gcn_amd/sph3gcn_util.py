@@ -183,6 +183,18 @@ def build_graph_deconv(xyz, xyz_unpool, radius, nn_uplimit):
     return intra_idx, intra_cnt, intra_dst, inter_idx, inter_cnt, inter_dst
 
 
+def build_intra_graph(xyz, radius, nn_uplimit, kernel):
+    """Intra-level graph + spherical-kernel bins of one point set: what the model graphs obtain from
+    ``neighbor_fn(xyz, xyz, ...)`` followed by ``spherical_kernel(xyz, xyz, ...)`` (models/SPH3D_s3dis.py:56-62), from ONE
+    fused kernel on the HIP device (tf_nnquery.build_sphere_graph); on other tensors (the CPU-oracle-backed tests) the two
+    calls are made one after the other.  -> nn_idx, nn_cnt, nn_dst, filt_idx"""
+    from . import tf_nnquery
+    if xyz.is_cuda and neighbor_fn is build_sphere_neighbor:
+        return tf_nnquery.build_sphere_graph(xyz, radius, nn_uplimit, kernel)
+    idx, cnt, dst = neighbor_fn(xyz, xyz, radius=radius, nnsample=nn_uplimit)
+    return idx, cnt, dst, spherical_kernel(xyz, xyz, idx, cnt, dst, radius, kernel=kernel)
+
+
 def gather_nd(params, indices):
     """tf.gather_nd for the [B, S, 2] (batch, point) index pairs build_graph returns
     (used by the model graphs at models/SPH3D_s3dis.py:68-72)."""

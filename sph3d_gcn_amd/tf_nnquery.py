@@ -115,3 +115,38 @@ def build_cube_neighbor(database, query, length=0.1, dilation_rate=None, nnsampl
     if dilation_rate is not None:
         length = dilation_rate * length
     return _build_cube_neighbor_impl(database, query, float(length), int(nnsample), int(gridsize))
+
+
+def build_sphere_graph(xyz, radius, nnsample, kernel, with_transpose=True):
+    """Fused graph construction of one level (not in the reference's API): the intra-level neighbour graph of
+    `xyz` AND its spherical-kernel bins from one kernel — the same tensors, bit for bit, as
+    ``build_sphere_neighbor(xyz, xyz, radius, None, nnsample)`` followed by ``spherical_kernel(xyz, xyz, ..., radius,
+    kernel)`` — and, with_transpose, the counting pass of the transposed graph the convolution gradients gather over (it is
+    finished and cached here, so the backward pass finds it ready).
+    -> nn_index, nn_count, nn_dist, filt_index"""
+    from . import _plan, _tgraph
+    xyz = _lib.f32(xyz[:, :, 0:3])
+    _lib.require_device(xyz)
+    if _radius_mode == "fixed":
+        raise ValueError("build_sphere_graph implements the reference (compat) radius semantics only")
+    n, p, q = (int(v) for v in kernel)
+    B, N, _ = xyz.shape
+    K = int(nnsample)
+    F = n * p * q + 1
+    dev = xyz.device
+    nn_index = torch.empty((B, N, K), dtype=torch.int32, device=dev)
+    nn_count = torch.empty((B, N), dtype=torch.int32, device=dev)
+    nn_dist = torch.empty((B, N, K), dtype=torch.float32, device=dev)
+    filt = torch.empty((B, N, K), dtype=torch.int32, device=dev)
+    l = _lib.lib()
+    ws, wsb = None, 0
+    if with_transpose:
+        wsb = l.sph3d_graph_transpose_workspace(B, N, N, K, F)
+        ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
+    _lib.check(l.sph3d_build_sphere_graph(B, N, N, K, float(radius), n, p, q, _lib.ptr(xyz), _lib.ptr(xyz), _lib.ptr(nn_index),
+                                          _lib.ptr(nn_count), _lib.ptr(nn_dist), _lib.ptr(filt), _lib.ptr(ws), wsb,
+                                          _lib.stream_ptr()))
+    _plan.register_geometry(filt, xyz, xyz)
+    if with_transpose:
+        _tgraph.transpose(nn_index, nn_count, N, bin_index=filt, num_bins=F, counted_workspace=ws)
+    return nn_index, nn_count, nn_dist, filt

@@ -133,6 +133,45 @@ def test_sphere_neighbor_fixed_radius_mode(dev, case):
     np.testing.assert_array_equal(_n(dst).view(np.int32), dst_o.view(np.int32))
 
 
+@pytest.mark.parametrize("case", [c for c in NN_CASES if c[3] is None] + [("s3dis", 16, 2048, None, 0.2, 64)],
+                         ids=lambda c: "%s-B%d-N%d-M%s-r%g-K%d" % c)
+def test_fused_graph_construction_equals_separate_ops(dev, case):
+    """sph3d_build_sphere_graph: neighbour search + bins (+ the transposed graph's counting pass) in one
+    kernel == build_sphere_neighbor -> spherical_kernel (-> graph_transpose), bit for bit; inside a (source, bin) segment
+    of the transposed graph the order is the arrival order of an atomic in both builds, so segments are compared as sets."""
+    from sph3d_gcn_amd import _tgraph
+    kind, B, N, _M, radius, K = case
+    xyz = _t(_clouds(kind, B, N, seed=5), dev)
+    for kernel in ([8, 2, 2], [4, 2, 1]):
+        F = kernel[0] * kernel[1] * kernel[2] + 1
+        idx, cnt, dst = tf_nnquery.build_sphere_neighbor(xyz, xyz, radius, None, K)
+        filt = tf_buildkernel.spherical_kernel(xyz, xyz, idx, cnt, dst, radius, kernel)
+        i2, c2, d2, f2 = tf_nnquery.build_sphere_graph(xyz, radius, K, kernel)
+        assert torch.equal(i2, idx) and torch.equal(c2, cnt) and torch.equal(d2.view(torch.int32), dst.view(torch.int32))
+        assert torch.equal(f2, filt)
+        off_a, key_a, sc_a, act_a = _tgraph.transpose(idx, cnt, N, bin_index=filt, num_bins=F)
+        off_b, key_b, sc_b, act_b = _tgraph.transpose(i2, c2, N, bin_index=f2, num_bins=F)      # cached by the fused op
+        assert torch.equal(off_a, off_b) and torch.equal(act_a[:1 + int(act_a[0])], act_b[:1 + int(act_b[0])])
+        oa, ka, kb = _n(off_a), _n(key_a), _n(key_b)
+        sa, sb = _n(sc_a), _n(sc_b)
+        seg = np.repeat(np.arange(len(oa) - 1), np.diff(oa).clip(min=0)) if B == 1 else None
+        # sort the entries of every segment: lexsort by (segment id, key)
+        total = B * N * K
+        segid = np.zeros(total, np.int64)
+        L = N * F
+        for b in range(B):
+            o = oa[b * (L + 1):(b + 1) * (L + 1)]
+            segid[o[0]:o[-1]] = np.repeat(np.arange(L) + b * L, np.diff(o))
+        used = np.zeros(total, bool)
+        for b in range(B):
+            o = oa[b * (L + 1):(b + 1) * (L + 1)]
+            used[o[0]:o[-1]] = True
+        pa = np.lexsort((ka[used], segid[used]))
+        pb = np.lexsort((kb[used], segid[used]))
+        np.testing.assert_array_equal(ka[used][pa], kb[used][pb])
+        np.testing.assert_array_equal(sa[used][pa], sb[used][pb])
+
+
 @pytest.mark.parametrize("B,N,M,K,L,G", [(2, 300, 100, 8, 0.3, 3), (1, 1000, 1000, 20, 0.1, 4), (3, 77, 5, 70, 0.9, 2)])
 def test_cube_neighbor_bitexact(dev, B, N, M, K, L, G):
     db = _clouds("uniform", B, N, seed=2)
