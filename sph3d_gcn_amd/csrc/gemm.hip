@@ -288,11 +288,17 @@ static void launch_gemm_tiles(int M, int N, int Kd, const float* A, int lda, con
         constexpr int BKX = BKL;
         hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 128, BKX, false, GUARD>), dim3((unsigned)ntiles(128, 128)), dim3(256), 0, st,
                            M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
+    } else if (BKM) {
+        // input-gradient product (W stored [n][k]): 64x64 tiles at every size.  Measured round 2 over the S3DIS shapes:
+        // 0.111 vs 0.139 ms at (131072, 256 -> 128), 0.098 vs 0.124 at (32768, 512 -> 256), 0.071 vs 0.088 at
+        // (6144, 2048 -> 256); never slower than the larger tiles
+        hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 64, 64, BKS, false, GUARD>), dim3((unsigned)ntiles(64, 64)), dim3(256), 0, st, M,
+                           N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
     } else if (N > 64 && ntiles(128, 128) >= 512) {
         constexpr int BKX = BKS;
         hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 128, BKX, false, GUARD>), dim3((unsigned)ntiles(128, 128)), dim3(256), 0, st,
                            M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
-    } else if (ntiles(128, 64) >= 512) {
+    } else if (N <= 64 && ntiles(128, 64) >= 512) {      // (wider outputs with fewer rows: 64x64, e.g. 0.092 vs 0.111 ms at (32768, 1024 -> 128))
         hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 64, BKS, false, GUARD>), dim3((unsigned)ntiles(128, 64)), dim3(256), 0, st,
                            M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
     } else {
