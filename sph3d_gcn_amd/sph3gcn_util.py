@@ -236,8 +236,8 @@ def separable_conv3d(inputs,
                      with_bias=False,
                      reuse=None,
                      is_training=None):
-    """ 3D separable convolution with non-linear operation (utils/sph3gcn_util.py:88-163):
-    depthwise spherical conv -> pointwise matmul -> (bias) -> activation -> (batch norm). """
+    """Separable spherical convolution layer (same signature as utils/sph3gcn_util.py:88-163): depthwise conv over the
+    graph, pointwise GEMM to `num_output_channels`, then bias / activation / batch norm as the flags say."""
     num_in_channels = inputs.shape[-1]
     depthwise_kernel = _variable_with_weight_decay(scope + '/depthwise_weights',
                                                    shape=[kernel_size, num_in_channels, depth_multiplier],
@@ -267,7 +267,7 @@ def pointwise_conv3d(inputs,
                      with_bias=False,
                      reuse=None,
                      is_training=None):
-    """ pointwise convolution with non-linear operation (utils/sph3gcn_util.py:166-222). """
+    """1x1 layer over the points: GEMM + bias / activation / batch norm (same signature as utils/sph3gcn_util.py:166-222)."""
     batch_size = inputs.shape[0]
     num_in_channels = inputs.shape[-1]
     kernel = _variable_with_weight_decay(scope + '/weights', shape=[num_in_channels, num_out_channels],
@@ -288,7 +288,7 @@ def fully_connected(inputs,
                     with_bias=False,
                     reuse=None,
                     is_training=None):
-    """ Fully connected layer with non-linear operation (utils/sph3gcn_util.py:225-273). """
+    """Dense layer on [B, C] features: GEMM + bias / activation / batch norm (same signature as utils/sph3gcn_util.py:225-273)."""
     num_in_channels = inputs.shape[-1]
     kernel = _variable_with_weight_decay(scope + '/weights', shape=[num_in_channels, num_out_channels],
                                          use_xavier=use_xavier, stddev=stddev, with_decay=weight_decay)
@@ -297,7 +297,7 @@ def fully_connected(inputs,
 
 
 def pool3d(inputs, nn_index, nn_count, scope, method):
-    """ 3D pooling (utils/sph3gcn_util.py:276-297). """
+    """Graph pooling onto the sampled points, method 'max' or 'avg' (same signature as utils/sph3gcn_util.py:276-297)."""
     if method == 'max':
         outputs, max_index = tf_pool3d.max_pool3d(inputs, nn_index, nn_count)
     elif method == 'avg':
@@ -308,7 +308,8 @@ def pool3d(inputs, nn_index, nn_count, scope, method):
 
 
 def unpool3d(inputs, nn_index, nn_count, nn_dist, scope, method):
-    """ 3D unpooling (utils/sph3gcn_util.py:300-325). """
+    """Feature interpolation back onto the finer point set, method 'mean' or 'weighted' (same signature as
+    utils/sph3gcn_util.py:300-325)."""
     if method == 'mean':
         outputs = tf_unpool3d.mean_interpolate(inputs, nn_index, nn_count)
     elif method == 'weighted':

@@ -58,18 +58,14 @@ def _(database, query, nn_index, nn_count, nn_dist, radius, n_azim, p_elev, q_ra
 
 
 def spherical_kernel(database, query, nn_index, nn_count, nn_dist, radius, kernel=[8, 2, 3]):
-    '''
-    Input:
-        database: (batch, npoint, 3+) float32 array, database points (x,y,z,...)
-        query:    (batch, mpoint, 3+) float32 array, query points (x,y,z,...)
-        nn_index: (batch, mpoint, nnsample) int32 array, neighbor indices
-        nn_count: (batch, mpoint) int32 array, number of neighbors
-        nn_dist: (batch, mpoint, nnsample) float32, sqrt distance array
-        radius:  float32, range search radius
-        kernel:   list of 3 int32, spherical kernel size
-    Output:
-        filt_index: (batch, mpoint, nnsample) int32 array, filter bin indices
-    '''
+    """Kernel bin of every graph edge (public signature of tf_buildkernel.py:10-30).
+
+    database [B, N, >=3], query [B, M, >=3] fp32; nn_index / nn_count / nn_dist as returned by build_sphere_neighbor
+    (nn_dist is the square-rooted distance and is compared with `radius` as it is); kernel = [n azimuth sectors,
+    p elevation bands, q radial shells].
+    returns  filt_index [B, M, K] int32 in [0, n*p*q]: 0 for the query point itself, otherwise 1 + a cell index built
+             from (shell, band, sector) as in csrc/sphere_bin.hpp.  No gradient.
+    """
     n, p, q = kernel
     database = database[:, :, 0:3]
     query = query[:, :, 0:3]

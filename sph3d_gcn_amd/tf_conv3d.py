@@ -139,16 +139,17 @@ class _DepthwiseConv3dFn(torch.autograd.Function):
 
 
 def depthwise_conv3d(input, filter, nn_index, nn_count, bin_index):
-    '''
-    Input:
-        input:   (batch, npoint, in_channels) float32 array, input point features
-        filter: (binsize, in_channels, channel_multiplier) float32 array, convolution filter
-        nn_index: (batch, mpoint, nnsample) int32 array, neighbor indices
-        nn_count: (batch, mpoint) int32 array, number of neighbors
-        bin_index: (batch, mpoint, nnsample), filtet bins' indices
-    Output:
-        output: (batch, mpoint, out_channels) float32 array, output point features
-    '''
+    """Depthwise half of the separable spherical convolution (public signature of tf_conv3d.py:9-20).
+
+    input      [B, N, C]  fp32  features of the N graph nodes
+    filter     [F, C, r]  fp32  one weight per (kernel bin, channel, multiplier); F = n*p*q + 1, bin 0 = the centre
+    nn_index   [B, M, K]  int32 neighbours of each of the M output nodes (first nn_count entries valid)
+    nn_count   [B, M]     int32
+    bin_index  [B, M, K]  int32 kernel bin of each neighbour (spherical_kernel / the cube search)
+    returns    [B, M, C*r] fp32: out[b,m,c*r+j] = 1/nn_count[b,m] * sum_k input[b,nn_index[b,m,k],c] * filter[bin_index[b,m,k],c,j]
+
+    Differentiable in `input` and `filter` (gradients through the transposed graph, see _tgraph.py).
+    """
     return _DepthwiseConv3dFn.apply(input, filter, nn_index, nn_count, bin_index)
 
 

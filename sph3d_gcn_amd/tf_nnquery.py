@@ -85,18 +85,17 @@ def _(database, query, length, nn_sample, grid_size):
 
 
 def build_sphere_neighbor(database, query, radius=0.1, dilation_rate=None, nnsample=100):
-    '''
-    Input:
-        database: (batch, npoint, 3+x) float32 array, database points
-        query:    (batch, mpoint, 3) float32 array, query points
-        radius:   float32, range search radius
-        dilation_rate: float32, dilation rate of range search
-        nnsample: int32, maximum number of neighbors to be sampled
-    Output:
-        nn_index: (batch, mpoint, nnsample) int32 array, neighbor indices
-        nn_count: (batch, mpoint) int32 array, number of neighbors
-        nn_dist: (batch, mpoint, nnsample) float32, sqrt distance array
-    '''
+    """Range search (public signature of tf_nnquery.py:9-31): for every query point the first `nnsample` database points,
+    in ascending index order, that lie strictly inside the search sphere.
+
+    database  [B, N, >=3] fp32 (only x, y, z are used)      query  [B, M, >=3] fp32
+    radius    search radius; multiplied by `dilation_rate` when that is given
+    returns   nn_index [B, M, nnsample] int32 (unused slots 0), nn_count [B, M] int32,
+              nn_dist  [B, M, nnsample] fp32 = SQUARE ROOT of the Euclidean distance (the reference's quirk, kept)
+
+    In the default "compat" mode the radius grows along each reference thread's chain of queries exactly as in the
+    reference kernel; see set_radius_mode.  No gradient.
+    """
     database = database[:, :, 0:3]
     query = query[:, :, 0:3]
     if dilation_rate is not None:
@@ -105,11 +104,11 @@ def build_sphere_neighbor(database, query, radius=0.1, dilation_rate=None, nnsam
 
 
 def build_cube_neighbor(database, query, length=0.1, dilation_rate=None, nnsample=100, gridsize=3):
-    '''
-    Output:
-        nn_index: (batch, mpoint, nnsample, 2) int32 array, neighbor and filter bin indices
-        nn_count: (batch, mpoint) int32 array, number of neighbors
-    '''
+    """Cube search (public signature of tf_nnquery.py:34-52): neighbours inside the axis-aligned cube of edge `length`
+    (times `dilation_rate` if given) around each query, with the cell of a gridsize^3 grid each one falls in.
+
+    returns   nn_index [B, M, nnsample, 2] int32 = (neighbour, grid cell), nn_count [B, M] int32.  No gradient.
+    """
     database = database[:, :, 0:3]
     query = query[:, :, 0:3]
     if dilation_rate is not None:

@@ -35,13 +35,11 @@ def _(database, npoint):
 
 
 def farthest_point_sample(neursize, database):
-    '''
-    input:
-        neursize: int32, the number of neurons/points to be sampled
-        database: (batch, npoint, 3) float32 array, database points
-    returns:
-        neuron_index: (batch_size, neursize) int32 array, index of sampled neurons in the database
-    '''
+    """Farthest-point sampling (public signature of tf_sample.py:15-23; note the argument order: count first).
+
+    database [B, N, 3] fp32 -> [B, neursize] int32: index 0 first, then repeatedly the point farthest from the chosen set
+    (ties: lower index within the reference's 1024-thread stride, then lower index).  No gradient.
+    """
     return _farthest_point_sample_impl(database, int(neursize))
 
 
