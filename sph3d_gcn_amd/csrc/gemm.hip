@@ -10,19 +10,25 @@
 //
 // MI355X design: v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain, no TF32-style truncation, so the
 // 1e-5 activation bound holds).  Workgroup = 4 waves, block tile 128x128 / 128x64 / 64x64 (the largest that still
-// gives all 256 CUs work: the row count shrinks 64-fold from level 0 to level 3), BK = 32 when the grid has >= 3
-// workgroups per CU (half the barriers) else 16 (more resident workgroups); each wave owns a quarter
-// of the tile as independent 32x32 accumulators.  Operand tiles go global -> registers (prefetch of tile t+1 during
+// gives all 256 CUs work: the row count shrinks 64-fold from level 0 to level 3), BK = 16 so that the 128x128 kernel
+// fits 128 VGPRs and 40 KB of LDS = FOUR workgroups per CU (BK = 32 at two per CU measured slower for all three
+// products); each wave owns a quarter of the tile as independent 32x32 accumulators.  Operand tiles go global -> registers (prefetch of tile t+1 during
 // the MFMAs of tile t) -> a double-buffered LDS image lds[row][k] (one barrier per k-tile) from which a lane's
 // operands for four MFMA steps are a single conflict-free ds_read_b128 (Stage / kmap comments below).
 // Ragged edges (Cin = 3, Cout = 13, R not a multiple of 128) take guarded scalar loads / stores.
 // TN splits R over workgroups; every split writes its partial tile to a workspace slab and a second kernel adds the
 // slabs in a fixed order (deterministic, no float atomics).
+#include <cstdlib>
 #include "common.hpp"
 
 namespace sph3d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// prefetch registers are NATIVE vectors: HIP's float4 is a struct, whole-struct copies become memcpy's through a private
+// array that the compiler then keeps in scratch memory (round 2: scratch_store behind every A-tile load of the main loop)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 as_v4(const float4 v) { f32x4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
 
 constexpr int BM = 128;
 constexpr int BKS = 16;      // k-tile for small grids (more workgroups per CU)
@@ -56,15 +62,21 @@ template <bool KMAJ, int BT, int BK>
 struct Stage {
     static constexpr int LDK = BK + 4;
     // KMAJ : one float4 (4 consecutive k of one row) per chunk, BT*BK/4 chunks, stored with ds_write_b128.
-    // !KMAJ: one 4(k) x 4(row) block per unit: four float4 loads along the row dimension (lanes with the same k-quad
-    //        cover 256 contiguous bytes), transposed in registers, stored as four ds_write_b128 along k.  Lane ->
-    //        (k-quad = lane % 4, row-quad = lane / 4) puts the 8 lanes of a b128 store group on 8 distinct 16-B bank
-    //        slots.  (Round-1 PMC: the earlier scalar transposing store was 16-way bank-conflicted, 77 % of LDS cycles.)
-    static constexpr int UNITS = KMAJ ? BT * BK / 4 : BT * BK / 16;
+    // !KMAJ: one KU(k) x 4(row) block per unit: KU float4 loads along the row dimension (lanes with the same k
+    //        cover contiguous bytes), transposed in registers, stored as four ds_write_b128 (KU = 4) or ds_write_b64
+    //        (KU = 2) along k.  Lane -> (k-unit = lane % (BK/KU), row-quad = lane / (BK/KU)) puts the lanes of a store
+    //        group on distinct bank slots.  (Round-1 PMC: the earlier scalar transposing store was 16-way
+    //        bank-conflicted, 77 % of LDS cycles.)  KU = 2 for BK = 16: every one of the 256 threads then holds 8 prefetch
+    //        registers for a 128-row tile instead of half of them holding 16 (the 128x128 kernel is at the 128-VGPR
+    //        limit of four workgroups per CU; round 2 found its A prefetch spilled to scratch with a vmcnt wait
+    //        right behind the load).
+    static constexpr int KU = KMAJ ? 4 : (BK == 16 ? 2 : 4);
+    static constexpr int KUN = BK / KU;                       // k-units per tile (!KMAJ), k-quads (KMAJ: BK/4)
+    static constexpr int UNITS = KMAJ ? BT * BK / 4 : (BT / 4) * KUN;
     static constexpr int NCH = (UNITS + 255) / 256;
-    static constexpr int NREG = KMAJ ? NCH : NCH * 4;
+    static constexpr int NREG = KMAJ ? NCH : NCH * KU;
     static constexpr int LDS_FLOATS = BT * LDK;
-    float4 r[NREG];
+    f32x4 r[NREG];
 
     template <bool GUARD>
     __device__ __forceinline__ void load(const float* __restrict__ p, int ld, int row0, int k0, int rows, int kdim, bool vec_ok)
@@ -73,21 +85,48 @@ struct Stage {
         for (int i = 0; i < NCH; i++) {
             const int u = (int)threadIdx.x + i * 256;
             if (KMAJ) {
-                if (UNITS < 256 && u >= UNITS) { r[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+                if (UNITS < 256 && u >= UNITS) { r[i] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
                 const int row = u / (BK / 4), kq = u % (BK / 4);
-                if (!GUARD) r[i] = *reinterpret_cast<const float4*>(p + (size_t)(row0 + row) * ld + k0 + kq * 4);
-                else r[i] = load4_guard(p, ld, row0 + row, k0 + kq * 4, rows, kdim, vec_ok);
+                if (!GUARD) r[i] = *reinterpret_cast<const f32x4*>(p + (size_t)(row0 + row) * ld + k0 + kq * 4);
+                else r[i] = as_v4(load4_guard(p, ld, row0 + row, k0 + kq * 4, rows, kdim, vec_ok));
             } else {
                 if (UNITS % 256 != 0 && u >= UNITS) {
 #pragma unroll
-                    for (int t = 0; t < 4; t++) r[i * 4 + t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int t = 0; t < KU; t++) r[i * KU + t] = f32x4{0.f, 0.f, 0.f, 0.f};
                     continue;
                 }
-                const int kq = u % (BK / 4), rq = u / (BK / 4);
+                const int kq = u % KUN, rq = u / KUN;
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    if (!GUARD) r[i * 4 + t] = *reinterpret_cast<const float4*>(p + (size_t)(k0 + kq * 4 + t) * ld + row0 + rq * 4);
-                    else r[i * 4 + t] = load4_guard(p, ld, k0 + kq * 4 + t, row0 + rq * 4, kdim, rows, vec_ok);
+                for (int t = 0; t < KU; t++) {
+                    if (!GUARD) r[i * KU + t] = *reinterpret_cast<const f32x4*>(p + (size_t)(k0 + kq * KU + t) * ld + row0 + rq * 4);
+                    else r[i * KU + t] = as_v4(load4_guard(p, ld, k0 + kq * KU + t, row0 + rq * 4, kdim, rows, vec_ok));
+                }
+            }
+        }
+    }
+
+    // Unguarded whole tiles: `base` is the WORKGROUP-UNIFORM address of the tile's (row0, k0) element (scalar registers,
+    // advanced by the caller with scalar adds), the lane's part is ONE loop-invariant 32-bit offset: the loads are
+    // global_load_dwordx4 v, v_off, s[base] instead of six 64-bit pointer VGPR pairs with a v_lshl_add_u64 each per tile.
+    __device__ __forceinline__ unsigned lane_offset(int ld) const
+    {
+        const int u = (int)threadIdx.x;
+        if (KMAJ) return (unsigned)((u / (BK / 4)) * ld + (u % (BK / 4)) * 4);
+        return (unsigned)((u % KUN) * KU * ld + (u / KUN) * 4);
+    }
+    __device__ __forceinline__ void load_fast(const float* __restrict__ base, int ld, unsigned voff)
+    {
+        if (UNITS < 256 && (int)threadIdx.x >= UNITS) return;      // (registers of idle threads are never stored)
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            if (KMAJ) {
+                const float* b = base + (size_t)(i * (256 / (BK / 4))) * ld;                // uniform
+                r[i] = *reinterpret_cast<const f32x4*>(b + voff);
+            } else {
+#pragma unroll
+                for (int t = 0; t < KU; t++) {
+                    const float* b = base + (size_t)t * ld + i * (256 / KUN) * 4;            // uniform
+                    r[i * KU + t] = *reinterpret_cast<const f32x4*>(b + voff);
                 }
             }
         }
@@ -100,16 +139,24 @@ struct Stage {
             if (KMAJ) {
                 if (UNITS < 256 && u >= UNITS) continue;
                 const int row = u / (BK / 4), kq = u % (BK / 4);
-                *reinterpret_cast<float4*>(lds + row * LDK + kq * 4) = r[i];
+                *reinterpret_cast<f32x4*>(lds + row * LDK + kq * 4) = r[i];
             } else {
                 if (UNITS % 256 != 0 && u >= UNITS) continue;
-                const int kq = u % (BK / 4), rq = u / (BK / 4);
-                const float4 a = r[i * 4], b = r[i * 4 + 1], c = r[i * 4 + 2], d = r[i * 4 + 3];   // k = 4kq + 0..3
-                float* base = lds + (rq * 4) * LDK + kq * 4;
-                *reinterpret_cast<float4*>(base) = make_float4(a.x, b.x, c.x, d.x);
-                *reinterpret_cast<float4*>(base + LDK) = make_float4(a.y, b.y, c.y, d.y);
-                *reinterpret_cast<float4*>(base + 2 * LDK) = make_float4(a.z, b.z, c.z, d.z);
-                *reinterpret_cast<float4*>(base + 3 * LDK) = make_float4(a.w, b.w, c.w, d.w);
+                const int kq = u % KUN, rq = u / KUN;
+                float* base = lds + (rq * 4) * LDK + kq * KU;
+                if (KU == 4) {
+                    const f32x4 a = r[i * 4], b = r[i * 4 + 1], c = r[i * 4 + 2], d = r[i * 4 + 3];   // k = 4kq + 0..3
+                    *reinterpret_cast<f32x4*>(base) = f32x4{a.x, b.x, c.x, d.x};
+                    *reinterpret_cast<f32x4*>(base + LDK) = f32x4{a.y, b.y, c.y, d.y};
+                    *reinterpret_cast<f32x4*>(base + 2 * LDK) = f32x4{a.z, b.z, c.z, d.z};
+                    *reinterpret_cast<f32x4*>(base + 3 * LDK) = f32x4{a.w, b.w, c.w, d.w};
+                } else {
+                    const f32x4 a = r[i * KU], b = r[i * KU + (KU > 1 ? 1 : 0)];                         // k = 2kq, 2kq + 1
+                    *reinterpret_cast<f32x2*>(base) = f32x2{a.x, b.x};
+                    *reinterpret_cast<f32x2*>(base + LDK) = f32x2{a.y, b.y};
+                    *reinterpret_cast<f32x2*>(base + 2 * LDK) = f32x2{a.z, b.z};
+                    *reinterpret_cast<f32x2*>(base + 3 * LDK) = f32x2{a.w, b.w};
+                }
             }
         }
     }
@@ -160,8 +207,19 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? 4 : 2) void gemm_f32_mf
     SA sa;
     SB sb;
     constexpr int BUF = SA::LDS_FLOATS + SB::LDS_FLOATS;     // buffer b: A image at lds + b*BUF, B image after it
-    sa.template load<GUARD>(A, lda, m0, k_begin, M, k_end, a_vec);
-    sb.template load<GUARD>(B, ldb, n0, k_begin, N, k_end, b_vec);
+    // unguarded tiles: uniform tile addresses + one loop-invariant lane offset per operand (Stage::load_fast)
+    const float* abase = AK ? A + (size_t)m0 * lda + k_begin : A + (size_t)k_begin * lda + m0;
+    const float* bbase = BKM ? B + (size_t)n0 * ldb + k_begin : B + (size_t)k_begin * ldb + n0;
+    const size_t astep = AK ? (size_t)BK : (size_t)BK * lda;
+    const size_t bstep = BKM ? (size_t)BK : (size_t)BK * ldb;
+    const unsigned aoff = sa.lane_offset(lda), boff = sb.lane_offset(ldb);
+    if (GUARD) {
+        sa.template load<GUARD>(A, lda, m0, k_begin, M, k_end, a_vec);
+        sb.template load<GUARD>(B, ldb, n0, k_begin, N, k_end, b_vec);
+    } else {
+        sa.load_fast(abase, lda, aoff);
+        sb.load_fast(bbase, ldb, boff);
+    }
     sa.store(lds);
     sb.store(lds + SA::LDS_FLOATS);
     __syncthreads();
@@ -170,18 +228,25 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? 4 : 2) void gemm_f32_mf
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         const bool more = (k0 + BK) < k_end;
         if (more) {                       // global -> registers for tile t+1 while tile t is multiplied
-            sa.template load<GUARD>(A, lda, m0, k0 + BK, M, k_end, a_vec);
-            sb.template load<GUARD>(B, ldb, n0, k0 + BK, N, k_end, b_vec);
+            if (GUARD) {
+                sa.template load<GUARD>(A, lda, m0, k0 + BK, M, k_end, a_vec);
+                sb.template load<GUARD>(B, ldb, n0, k0 + BK, N, k_end, b_vec);
+            } else {
+                abase += astep;
+                bbase += bstep;
+                sa.load_fast(abase, lda, aoff);
+                sb.load_fast(bbase, ldb, boff);
+            }
         }
         const float* ca = lds + buf * BUF;
         const float* cb = ca + SA::LDS_FLOATS;
 #pragma unroll
         for (int g = 0; g < BK / 8; g++) {
-            float4 af[TM], bf[TN];
+            f32x4 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const float4*>(ca + (wm + i * 32 + li) * LDK + g * 8 + lk * 4);
+            for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const f32x4*>(ca + (wm + i * 32 + li) * LDK + g * 8 + lk * 4);
 #pragma unroll
-            for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const float4*>(cb + (wn + j * 32 + li) * LDK + g * 8 + lk * 4);
+            for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const f32x4*>(cb + (wn + j * 32 + li) * LDK + g * 8 + lk * 4);
 #pragma unroll
             for (int s4 = 0; s4 < 4; s4++) {
 #pragma unroll
@@ -284,14 +349,13 @@ static void launch_gemm_tiles(int M, int N, int Kd, const float* A, int lda, con
     // tile choice: the largest tile that still gives every CU TWO workgroups (measured: with >= 256 tiles as the rule the
     // mid-size levels ran 50 TF, with >= 512 they run 80-90 TF: one partial wave of workgroups leaves half the CUs idle)
     auto ntiles = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-    if (false) {        // (BK = 32 for the big grids was measured equal or slower than BK = 16 at 4 workgroups per CU)
-        constexpr int BKX = BKL;
-        hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 128, BKX, false, GUARD>), dim3((unsigned)ntiles(128, 128)), dim3(256), 0, st,
-                           M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
-    } else if (BKM) {
-        // input-gradient product (W stored [n][k]): 64x64 tiles at every size.  Measured round 2 over the S3DIS shapes:
-        // 0.111 vs 0.139 ms at (131072, 256 -> 128), 0.098 vs 0.124 at (32768, 512 -> 256), 0.071 vs 0.088 at
-        // (6144, 2048 -> 256); never slower than the larger tiles
+    // (BK = 32 at two workgroups per CU for the big grids: measured slower than BK = 16 at four, before and after the
+    //  round-2 register fix: 0.101 vs 0.094 ms at (131072, 256 -> 128))
+    if (BKM && !(N > 64 && ntiles(128, 128) >= 512)) {
+        // input-gradient product (W stored [n][k]) below 2 big tiles per CU: 64x64 tiles (0.071 vs 0.088 ms at
+        // (6144, 2048 -> 256) ... ) -- with >= 512 big tiles the 128x128 kernel wins since its prefetch registers stopped
+        // going through scratch: 0.100 vs 0.106 ms at (131072, 256 -> 128), 0.089 vs 0.098 at (32768, 512 -> 256),
+        // 0.062 vs 0.071 at (6144, 256 -> 2048)
         hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 64, 64, BKS, false, GUARD>), dim3((unsigned)ntiles(64, 64)), dim3(256), 0, st, M,
                            N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
     } else if (N > 64 && ntiles(128, 128) >= 512) {
@@ -378,8 +442,15 @@ extern "C" int sph3d_pointwise_gemm_tn(int R, int Cin, int Cout, const float* X,
 #define SPH3D_TN(BNN, G)                                                                                                   \
     hipLaunchKernelGGL((gemm_f32_mfma<false, false, 128, BNN, BKL, true, G>), dim3(tiles, nsplit), dim3(256), 0, st, Cin, Cout, R, X, \
                        Cin, dY, Cout, out, Cout, nullptr, 0, kchunk)
-    if (bn == 128) { if (whole) SPH3D_TN(128, false); else SPH3D_TN(128, true); }
-    else { if (whole) SPH3D_TN(64, false); else SPH3D_TN(64, true); }
+#define SPH3D_TN16(BNN)                                                                                                    \
+    hipLaunchKernelGGL((gemm_f32_mfma<false, false, 128, BNN, BKS, true, false>), dim3(tiles, nsplit), dim3(256), 0, st, Cin, Cout, R, X, \
+                       Cin, dY, Cout, out, Cout, nullptr, 0, kchunk)
+    // whole tiles: BK = 16 at four workgroups per CU (8 + 8 prefetch registers with the 2x4 transposing units): 0.786 vs
+    // 0.855 ms over the step's shapes against BK = 32 at two per CU
+    if (whole) { if (bn == 128) SPH3D_TN16(128); else SPH3D_TN16(64); }
+    else if (bn == 128) SPH3D_TN(128, true);
+    else SPH3D_TN(64, true);
+#undef SPH3D_TN16
 #undef SPH3D_TN
     if (nsplit > 1) {
         const int total = Cin * Cout;
