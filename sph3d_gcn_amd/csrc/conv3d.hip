@@ -397,11 +397,11 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
 
     const int wave = uniform((int)threadIdx.x >> 6);
     const int lane = lane_id();
+    const int stride = W * kBwdTWaves;          // waves of this XCD that sweep a cloud side by side
     const int half = HALF ? (lane >> 5) : 0;
     const int cl0 = (HALF ? (lane & 31) : lane) * V;
     const bool act = cl0 < SL;
     const int cin0 = (slice0 + cl0) / R;
-    const int stride = W * kBwdTWaves;          // waves of this XCD that sweep a cloud side by side
     // per-lane gradient-of-filter accumulators, one row per bin; every index below is a compile-time constant
     // (the bin loop is fully unrolled), so the table lives in VGPRs
     float acc[MAXF][V];
@@ -410,15 +410,26 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
 #pragma unroll
         for (int v = 0; v < V; v++) acc[i][v] = 0.f;
 
+    // COMPACT: lane i holds the bin of accumulator row i (one load for the whole launch; the per-segment scalar load of
+    // activeBins[1 + fi] was not hoisted by the compiler and put an s_load + lgkmcnt(0) in front of every segment)
+    const int abv = COMPACT ? activeBins[1 + (lane < MAXF ? lane : 0)] : 0;
+
     // Work items of this XCD: (cloud, part) pairs dealt round-robin; a part is a contiguous range of POSITIONS in the
     // processing order (source_order, or the point index).  Wave gw visits positions gw, gw + stride, ...; the
     // accumulators live across ALL items, so a workgroup writes one partial table for the whole launch.
+    // (Measured round 2 and dropped: handing the positions out dynamically through one ticket counter per item.  The
+    // static interleave leaves the busiest wave of an XCD with 1.4x the mean number of in-edges — the in-degree is
+    // heavy-tailed: level 0 mean 48, sigma 45, max 537, tools/exp_bwd_balance.py — but with tickets of 4 or 8 positions
+    // the level-0 kernels ran 0.66 / 0.55 ms against 0.53 / 0.35 ms, with or without waiting for the atomic at once.)
     for (int item = xcd; item < B * parts; item += 8) {
     const int b = item / parts;
     const int pi = item - b * parts;
     const int p_begin = (int)((long long)pi * N / parts);
     const int p_end = (int)((long long)(pi + 1) * N / parts);
-    const float* gob = gradOutput + (size_t)b * M * CR + slice0 + (act ? cl0 : 0);
+    // wave-uniform base of this cloud's grad_out rows + the lane's column: row gathers are uniform base + uniform row
+    // offset (an SGPR pair) + one loop-invariant 32-bit lane offset
+    const float* __restrict__ gou = gradOutput + (size_t)b * M * CR + slice0;
+    const unsigned cla = (unsigned)(act ? cl0 : 0);
     const int* __restrict__ offb = offsets + (size_t)b * ((size_t)N * F + 1);
     for (int p = p_begin + w * kBwdTWaves + wave; p < p_end; p += stride) {
         const int n = order ? uniform(order[(size_t)b * N + p]) : p;
@@ -435,38 +446,54 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
         float gi[V];
 #pragma unroll
         for (int v = 0; v < V; v++) gi[v] = 0.f;
+        // The source's in-edges are one contiguous run [E0, E1) of the (source, bin)-sorted entry arrays.  Their keys
+        // and scales are fetched 64 at a time with ONE coalesced vector load each (lane = edge) and handed to the
+        // gathers with v_readlane.  Round 2 counters on the scalar version of this loop (s_load of key and scale per
+        // edge, 64-bit scalar address arithmetic, clamps): 16.8 scalar-ALU + 2.7 scalar-memory instructions per edge =
+        // half of the CU's one-per-cycle scalar issue for the whole kernel, and a dependent s_load -> gather round
+        // trip per batch of four edges.
+        const int E0 = __builtin_amdgcn_readlane(ov0, 0);
+        const int E1 = uniform(o[F]);
+        for (int cb = E0; cb < E1; cb += 64) {
+        const int cn = (E1 - cb) < 64 ? (E1 - cb) : 64;
+        const int li = lane < cn ? lane : 0;
+        const unsigned kel = (unsigned)entKey[cb + li] * (unsigned)CR;     // row offset in floats (M * CR < 2^32, checked by the launcher)
+        const float svl = entScale[cb + li];
+        const float sv = lane < cn ? svl : 0.f;
 #pragma unroll
         for (int fi = 0; fi < MAXF; fi++) {
             if (fi < (COMPACT ? A : F)) {
                 // COMPACT: row fi of the accumulators belongs to bin activeBins[1 + fi] (wave-uniform, F <= 63)
-                const int f = COMPACT ? uniform(activeBins[1 + fi]) : fi;
-                const int e0 = COMPACT ? __builtin_amdgcn_readlane(ov0, f)
+                const int f = COMPACT ? __builtin_amdgcn_readlane(abv, fi) : fi;
+                const int a0 = COMPACT ? __builtin_amdgcn_readlane(ov0, f)
                                        : __builtin_amdgcn_readlane(fi < 64 ? ov0 : ov1, fi & 63);
-                const int e1 = COMPACT ? __builtin_amdgcn_readlane(ov0, f + 1)
+                const int a1 = COMPACT ? __builtin_amdgcn_readlane(ov0, f + 1)
                                        : __builtin_amdgcn_readlane((fi + 1) < 64 ? ov0 : ov1, (fi + 1) & 63);
+                // the part of the segment inside this chunk, as lane numbers
+                const int e0 = (a0 > cb ? a0 : cb) - cb;
+                const int e1 = (a1 < cb + cn ? a1 : cb + cn) - cb;
                 if (e0 < e1) {                               // wave-uniform: most (n, bin) segments are empty or short
                     float sg[V];
 #pragma unroll
                     for (int v = 0; v < V; v++) sg[v] = 0.f;
                     if (HALF) {
+                        // the two half-waves take alternate edges: lane-half h reads edge e + 2u + h of the chunk through
+                        // ds_bpermute (lane number modulo 64, scales masked to the segment: see the full-wave branch)
                         constexpr int NL = SPH3D_BWD_NL;          // wave loads per batch = 2 * NL edges
+                        const float svh = ((unsigned)(lane - e0) < (unsigned)(e1 - e0)) ? sv : 0.f;
                         for (int e = e0; e < e1; e += 2 * NL) {
-                            int mm[NL];
+                            const int a4 = ((e + half) << 2);
+                            unsigned ko[NL];
                             float sc[NL];
 #pragma unroll
                             for (int u = 0; u < NL; u++) {
-                                const int ia = e + 2 * u, ib = ia + 1;
-                                const int ca = ia < e1 ? ia : (e1 - 1), cb = ib < e1 ? ib : (e1 - 1);
-                                const int ma = entKey[ca], mb = entKey[cb];
-                                const float sa = ia < e1 ? entScale[ca] : 0.f;      // padding edges contribute exactly 0
-                                const float sb = ib < e1 ? entScale[cb] : 0.f;
-                                mm[u] = half ? mb : ma;
-                                sc[u] = half ? sb : sa;
+                                ko[u] = (unsigned)__builtin_amdgcn_ds_bpermute(a4 + 8 * u, (int)kel);
+                                sc[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(a4 + 8 * u, __float_as_int(svh)));
                             }
                             float g[NL][V];
 #pragma unroll
                             for (int u = 0; u < NL; u++) {
-                                const float4 t = *reinterpret_cast<const float4*>(&gob[(unsigned)mm[u] * (unsigned)CR]);
+                                const float4 t = *reinterpret_cast<const float4*>(&gou[ko[u] + cla]);
                                 g[u][0] = t.x; g[u][1 % V] = t.y; g[u][2 % V] = t.z; g[u][3 % V] = t.w;
                             }
 #pragma unroll
@@ -474,35 +501,36 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
 #pragma unroll
                                 for (int v = 0; v < V; v++) sg[v] = fmaf(g[u][v], sc[u], sg[v]);
                         }
-                    } else
+                    } else {
+                    // scales of THIS segment's lanes, zero elsewhere: a batch may then run past the segment end (and, as
+                    // v_readlane takes the lane number modulo 64, wrap to lanes below e0) without clamps or selects:
+                    // the extra gathers hit valid rows (every lane holds a valid key) and are multiplied by exactly 0
+                    const float svm = ((unsigned)(lane - e0) < (unsigned)(e1 - e0)) ? sv : 0.f;
                     for (int e = e0; e < e1; e += 4) {
                         // four edges at a time: their row gathers are independent and issued together
-                        int mm[4];
                         float sc[4];
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const int ee = (e + u) < e1 ? (e + u) : (e1 - 1);
-                            mm[u] = entKey[ee];
-                            sc[u] = (e + u) < e1 ? entScale[ee] : 0.f;      // padding edges contribute exactly 0
-                        }
                         float g[4][V];
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
+                            const unsigned ko = (unsigned)__builtin_amdgcn_readlane((int)kel, e + u);
+                            sc[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(svm), e + u));
+                            const float* __restrict__ rp = gou + ko;                // wave-uniform row address
                             // branch-free (inactive lanes read lane 0's columns): the four gathers stay in one basic block
                             if (V == 4) {
-                                const float4 t = *reinterpret_cast<const float4*>(&gob[(size_t)mm[u] * CR]);
+                                const float4 t = *reinterpret_cast<const float4*>(&rp[cla]);
                                 g[u][0] = t.x; g[u][1 % V] = t.y; g[u][2 % V] = t.z; g[u][3 % V] = t.w;
                             } else if (V == 2) {
-                                const float2 t = *reinterpret_cast<const float2*>(&gob[(size_t)mm[u] * CR]);
+                                const float2 t = *reinterpret_cast<const float2*>(&rp[cla]);
                                 g[u][0] = t.x; g[u][1 % V] = t.y;
                             } else {
-                                g[u][0] = gob[(size_t)mm[u] * CR];
+                                g[u][0] = rp[cla];
                             }
                         }
 #pragma unroll
                         for (int u = 0; u < 4; u++)
 #pragma unroll
                             for (int v = 0; v < V; v++) sg[v] = fmaf(g[u][v], sc[u], sg[v]);
+                    }
                     }
                     const float* wrow = &lfilt[f * SL + (act ? cl0 : 0)];
 #pragma unroll
@@ -513,6 +541,7 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
                 }
             }
         }
+        }   // chunks of 64 in-edges
         if (HALF) {
 #pragma unroll
             for (int v = 0; v < V; v++) gi[v] += __shfl_xor(gi[v], 32);
@@ -857,7 +886,8 @@ extern "C" int sph3d_depthwise_conv3d_grad_t(int B, int N, int M, int F, int C, 
     const int CR = C * r;
     if (B == 0) return check_hip(hipMemsetAsync(grad_filter, 0, sizeof(float) * (size_t)F * CR, st), "conv3d grad: memset");
     int V = 0;
-    if (vec_plan(F, CR, r, V)) {
+    // (the vector kernels address a cloud's grad_out rows with 32-bit element offsets)
+    if (vec_plan(F, CR, r, V) && (unsigned long long)M * CR + 256ull < (1ull << 32)) {
         const size_t need = sph3d_depthwise_conv3d_grad_t_workspace(B, N, F, C, r);
         if (workspace == nullptr || workspace_bytes < need) {
             set_error("DepthwiseConv3dGrad: workspace %zu B < required %zu B", workspace_bytes, need);
