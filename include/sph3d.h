@@ -237,6 +237,12 @@ int sph3d_farthest_point_sample(int b, int n, int m, const float* inp, int* out,
                                 void* workspace, size_t workspace_bytes,
                                 sph3d_stream_t stream);
 
+/* tf.gather_nd with [.., 2] (cloud, point) index pairs, as the model graphs use it on coordinates, neighbour lists and
+ * counts of the sampled points (models/SPH3D_s3dis.py:68-72; TensorFlow's stock op in the reference): params is
+ * [B, N, row] 4-byte elements, pairs [S, 2] int32, out [S, row].  Out-of-range pairs are clamped. */
+int sph3d_gather_nd(int B, int N, long long S, int row, const int* pairs, const void* params, void* out,
+                    sph3d_stream_t stream);
+
 /* ---- LDS-tiled depthwise convolution (tile.hip, convtile.hip) ---------------------------------------
  * Same results as sph3d_depthwise_conv3d (tf_ops/convolution/tf_conv3d_gpu.cu:7-29), for callers that keep a graph
  * across calls: a per-graph TILE PLAN lets the kernels stage

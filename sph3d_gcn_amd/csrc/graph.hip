@@ -254,6 +254,36 @@ extern "C" int sph3d_graph_transpose_finish(int B, int N, int M, int K, int F,
     return check_launch("sph3d_graph_transpose");
 }
 
+// tf.gather_nd for (cloud, point) index pairs: out[b, s, :] = params[pair.b, pair.p, :] for rows of `row` 4-byte elements
+// (coordinates, neighbour lists, counts: models/SPH3D_s3dis.py:68-72 gathers the sampled points' rows this way).
+// One launch instead of two int32 -> int64 conversions plus an advanced-indexing kernel per tensor.
+__global__ __launch_bounds__(256) void gather_nd_rows(int B, int N, long long total, int row, const int* __restrict__ pairs,
+                                                      const unsigned* __restrict__ params, unsigned* __restrict__ out)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const long long s = e / row;
+        const int c = (int)(e - s * row);
+        int b = pairs[s * 2], p = pairs[s * 2 + 1];
+        b = b < 0 ? 0 : (b >= B ? B - 1 : b);          // out-of-range pairs are clamped, never read outside params
+        p = p < 0 ? 0 : (p >= N ? N - 1 : p);
+        out[e] = params[((size_t)b * N + p) * row + c];
+    }
+}
+
+extern "C" int sph3d_gather_nd(int B, int N, long long S, int row, const int* pairs, const void* params, void* out,
+                               sph3d_stream_t stream)
+{
+    SPH3D_REQUIRE(B > 0 && N > 0 && S >= 0 && row > 0, "gather_nd: bad dims B=%d N=%d S=%lld row=%d", B, N, S, row);
+    const long long total = S * row;
+    if (total == 0) return SPH3D_OK;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gather_nd_rows, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), B, N, total, row, pairs,
+                       (const unsigned*)params, (unsigned*)out);
+    return check_launch("sph3d_gather_nd");
+}
+
 extern "C" int sph3d_graph_transpose(int B, int N, int M, int K, int F,
                                      const int* nn_index, const int* nn_count, const int* bin_index,
                                      const float* weight, int* offsets, int* ent_key, float* ent_scale, int* active_bins,

@@ -22,7 +22,7 @@ from . import tf_conv3d, tf_pool3d, tf_unpool3d
 from .tf_nnquery import build_sphere_neighbor, build_cube_neighbor
 from .tf_sample import farthest_point_sample, inverse_density_sample, random_sample
 from .tf_buildkernel import spherical_kernel
-from . import tf_gemm, tf_norm
+from . import tf_gemm, tf_norm, _lib
 
 neighbor_fn = build_sphere_neighbor  # default nn search method
 
@@ -198,6 +198,21 @@ def build_intra_graph(xyz, radius, nn_uplimit, kernel):
 def gather_nd(params, indices):
     """tf.gather_nd for the [B, S, 2] (batch, point) index pairs build_graph returns
     (used by the model graphs at models/SPH3D_s3dis.py:68-72)."""
+    if (params.is_cuda and params.dim() >= 2 and params.element_size() == 4 and indices.dtype == torch.int32
+            and indices.shape[-1] == 2 and not params.requires_grad):
+        # one HIP launch (sph3d_gather_nd) instead of two int64 conversions + an advanced-indexing kernel
+        params = params.contiguous()
+        indices = indices.contiguous()
+        B, N = params.shape[0], params.shape[1]
+        row = 1
+        for d in params.shape[2:]:
+            row *= d
+        S = indices.numel() // 2
+        out = torch.empty(tuple(indices.shape[:-1]) + tuple(params.shape[2:]), dtype=params.dtype, device=params.device)
+        if S and row:
+            _lib.check(_lib.lib().sph3d_gather_nd(B, N, S, row, _lib.ptr(indices), _lib.ptr(params), _lib.ptr(out),
+                                                 _lib.stream_ptr()))
+        return out
     b = indices[..., 0].long()
     p = indices[..., 1].long()
     return params[b, p]

@@ -697,3 +697,23 @@ def test_model_graphs_end_to_end_vs_oracle(dev, kind):
     for n in grads_o:
         s = max(1e-3, float(np.abs(grads_o[n]).max()))
         np.testing.assert_allclose(grads[n] / s, grads_o[n] / s, rtol=0, atol=5e-3, err_msg=n)
+
+
+@pytest.mark.gpu
+def test_gather_nd_kernel_matches_indexing(dev):
+    """sph3gcn_util.gather_nd on the device (sph3d_gather_nd) = tf.gather_nd semantics for (cloud, point) pairs: rows of
+    coordinates, neighbour lists and counts, bit for bit against torch indexing; the [B,S,2] pairs come from build_graph"""
+    from sph3d_gcn_amd import sph3gcn_util as s3g_util
+    g = torch.Generator().manual_seed(3)
+    B, N, S = 5, 700, 129
+    pairs = torch.stack([torch.arange(B).view(B, 1).expand(B, S), torch.randint(0, N, (B, S), generator=g)], dim=-1).int().to(dev)
+    for shape, dt in (((B, N, 3), torch.float32), ((B, N, 64), torch.int32), ((B, N), torch.int32), ((B, N, 4, 5), torch.float32)):
+        src = (torch.rand(shape, generator=g) * 1000).to(dt).to(dev)
+        got = s3g_util.gather_nd(src, pairs)
+        want = src[pairs[..., 0].long(), pairs[..., 1].long()]
+        assert got.dtype == src.dtype and got.shape == want.shape
+        assert torch.equal(got, want)
+    # a permuted batch column (pairs need not be sorted by cloud)
+    perm = pairs.flip(0).contiguous()
+    src = torch.rand((B, N, 7), generator=g).to(dev)
+    assert torch.equal(s3g_util.gather_nd(src, perm), src[perm[..., 0].long(), perm[..., 1].long()])
