@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsph3d.so")
+# SPH3D_LIB: another build of the same library (A/B measurements of kernel variants); there is still no non-HIP path
+LIB_PATH = os.environ.get("SPH3D_LIB") or os.path.join(_HERE, "csrc", "libsph3d.so")
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float

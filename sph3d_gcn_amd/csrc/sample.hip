@@ -61,6 +61,10 @@ struct __attribute__((aligned(16))) FpsSlot16 {
     float x, y, z;
 };
 
+// (Round 2: capping this kernel and the fused neighbour search at 64 VGPRs, so that a CU hosting one of their 16-wave
+// workgroups keeps room for two 128-VGPR waves per SIMD of the feature path, cut the slow-down of a GEMM running beside
+// the FPS chain from 1.2x to 1.07x (tools/exp_gemm_fps.py) but the training step got 0.5 % slower: A/B in one call,
+// tools/gpu_ab.sh.  Not kept.)
 template <int P>
 __global__ __launch_bounds__(1024) void fps_reg_kernel(int b, int n, int m,
                                                        const float* __restrict__ dataset, int* __restrict__ idxs)
