@@ -105,6 +105,13 @@ class GraphPlan:
                 streams = _side_stream[xyz.device] = (torch.cuda.Stream(device=xyz.device),
                                                       torch.cuda.Stream(device=xyz.device))
             s_fps, s_graph = streams
+            # (Measured round 2, A/B in one gpurun call: the level-0 search kernel — one 1024-thread, 112-KB-LDS workgroup
+            # per CU — cannot share a CU with a resident FPS workgroup (16 + 16 waves at 72 VGPRs), so beside the FPS chain
+            # its last 16 workgroups run as a second round: 1.15 ms instead of 0.62 (tools/exp_graph_fps.py).  Running the
+            # search IN FRONT of the chain — on the graph stream with an event, or on the sampling stream itself — made the
+            # step slower, 1440 / 1457 vs 1478 blocks/s: the 2.9-ms sampling chain is what the deeper graph levels wait for,
+            # and 0.6 ms more in front of it costs more than the search's second round.  Capping both kernels at 64 VGPRs so
+            # that they do share a CU: 1467 vs 1475.  Left as it is.)
             if points_ready is not None:
                 s_fps.wait_event(points_ready)
                 s_graph.wait_event(points_ready)

@@ -1,0 +1,60 @@
+"""Timeline analysis of a rocprofv3 kernel trace of bench.py: per queue busy time, idle gaps of the busiest (feature-path)
+queue, and for every kernel of that queue how much of its duration overlapped kernels of the other queues.
+usage: python tools/analyze_trace.py <kernel_trace.csv> [first_step_fraction_to_skip]"""
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), r["Kernel_Name"]) for r in rows]
+ev.sort()
+# steady-state window: one fps_reg_kernel<8> launch per training step; steps 20..28 of the run lie inside bench.py's
+# timed region (16 priming + 2 warm-up steps come first)
+marks = [e[0] for e in ev if "fps_reg_kernel<8>" in e[3]]
+lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (20, 28)
+nsteps = hi - lo
+ev = [e for e in ev if marks[lo] <= e[0] < marks[hi]]
+span = (max(e[1] for e in ev) - ev[0][0]) / 1e6
+byq = collections.defaultdict(list)
+for e in ev: byq[e[2]].append(e)
+print("window %.2f ms = %d steps of %.2f ms, %d kernels" % (span, nsteps, span / nsteps, len(ev)))
+busy = {}
+for q, l in byq.items():
+    b = 0; end = 0
+    for s, e, _, _ in l:
+        if e > end: b += e - max(s, end); end = e
+    busy[q] = b / 1e6
+    print("queue %d: %5d kernels, busy %.2f ms (%.0f %% of the window), sum of durations %.2f ms" % (q, len(l), busy[q], 100 * busy[q] / span, sum(e - s for s, e, _, _ in l) / 1e6))
+main = max(busy, key=lambda q: len(byq[q]))
+l = byq[main]
+gaps = [l[i + 1][0] - max(x[1] for x in l[:i + 1][-4:]) for i in range(len(l) - 1)]
+gaps = [g for g in gaps if g > 0]
+print("main queue %d: idle between kernels %.2f ms in %d gaps (median %.1f us, >20 us: %d gaps = %.2f ms)" % (
+    main, sum(gaps) / 1e6, len(gaps), sorted(gaps)[len(gaps) // 2] / 1e3, sum(1 for g in gaps if g > 20000), sum(g for g in gaps if g > 20000) / 1e6))
+others = sorted((s, e) for q, ll in byq.items() if q != main for s, e, _, _ in ll)
+def overlap(s, e):
+    o = 0
+    for a, b in others:
+        if a >= e: break
+        if b > s: o += min(b, e) - max(a, s)
+    return o
+agg = collections.defaultdict(lambda: [0, 0, 0, 0])
+import bisect
+starts = [a for a, b in others]
+for s, e, _, name in l:
+    i = max(0, bisect.bisect_left(starts, s) - 64)
+    o = 0
+    for a, b in others[i:]:
+        if a >= e: break
+        if b > s: o += min(b, e) - max(a, s)
+    k = name.split("(")[0][-60:]
+    a = agg[k]; a[0] += 1; a[1] += e - s; a[2] += min(o, e - s)
+print("main-queue kernels: calls, total ms, share of their time during which a side-queue kernel was running")
+for k, a in sorted(agg.items(), key=lambda x: -x[1][1])[:22]:
+    print("  %-62s %5d %7.2f ms  %3.0f %%" % (k, a[0], a[1] / 1e6, 100 * a[2] / max(a[1], 1)))
+for q, ll in byq.items():
+    if q == main: continue
+    agg2 = collections.defaultdict(lambda: [0, 0])
+    for s, e, _, name in ll:
+        k = name.split("(")[0][-60:]
+        agg2[k][0] += 1; agg2[k][1] += e - s
+    print("side queue %d, per step:" % q)
+    for k, a in sorted(agg2.items(), key=lambda x: -x[1][1])[:12]:
+        print("  %-62s %5.1f calls %6.3f ms" % (k, a[0] / nsteps, a[1] / 1e6 / nsteps))
