@@ -82,7 +82,8 @@ int sph3d_build_cube_neighbor(int B, int N, int M, int grid_size, int nn_sample,
  * transpose_workspace is given (sph3d_graph_transpose_workspace bytes) — the counting pass of the transposed graph as
  * well (finish it with sph3d_graph_transpose_finish).  Outputs equal, bit for bit, sph3d_build_sphere_neighbor followed by
  * sph3d_spherical_kernel(n, p, q, radius) on the same database / query; shapes whose per-query hit lists do not fit LDS
- * run those kernels one after the other. */
+ * run those kernels one after the other.  filt_index == NULL: no bins (an inter-level graph, n / p / q ignored): the
+ * search plus the counting pass for F = 1 (transpose_workspace is then required). */
 int sph3d_build_sphere_graph(int B, int N, int M, int nn_sample, float radius, int n, int p, int q,
                              const float* database, const float* query,
                              int* nn_index, int* nn_count, float* nn_dist, int* filt_index,

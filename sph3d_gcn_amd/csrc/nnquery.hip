@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
                                     const float d2 = (dx * dx + dy * dy) + dz * dz;   // tf_nnquery_gpu.cu:45-46
                                     dist = sqrtf(sqrtf(d2));                          // :47 then :54 — sqrt of the distance
                                     if (FUSE) {
-                                        bin = sphere_bin<false>(dx, dy, dz, dist, fx.radius, fx.n, fx.p, fx.q);
+                                        if (fx.filt != nullptr) bin = sphere_bin<false>(dx, dy, dz, dist, fx.radius, fx.n, fx.p, fx.q);
                                         if (fx.deg != nullptr) {
                                             fx.slotPos[row * K + slot] = atomicAdd(&fx.deg[((size_t)i * N + id) * fx.F + bin], 1);
                                             fx.binUsed[bin] = 1;          // benign race: every writer stores 1
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
                                 }
                                 nnIndex[row * K + slot] = id;                          // unused slots read 0
                                 nnDist[row * K + slot] = dist;
-                                if (FUSE) fx.filt[row * K + slot] = bin;
+                                if (FUSE && fx.filt != nullptr) fx.filt[row * K + slot] = bin;
                             }
                         } else {
                             for (int slot = cnt + lane; slot < K; slot += 64) {   // unused slots read 0
@@ -419,10 +419,16 @@ extern "C" int sph3d_build_sphere_graph(int B, int N, int M, int nn_sample, floa
                                         int* nn_index, int* nn_count, float* nn_dist, int* filt_index,
                                         void* transpose_workspace, size_t transpose_workspace_bytes, sph3d_stream_t stream)
 {
-    SPH3D_REQUIRE(n > 2 && n % 2 == 0, "Need n_>2 and n_%%2==0, got %d", n);               // tf_buildkernel.cpp:43
-    SPH3D_REQUIRE(p > 0 && p % 2 == 0, "Need p_>0 and p_%%2==0, got %d", p);               // :46
-    SPH3D_REQUIRE(q > 0, "Need q_>0, got %d", q);                                          // :49
-    const int F = n * p * q + 1;
+    // filt_index == NULL: no bins (an inter-level graph: one segment per source point), only the search and the counts
+    const bool binned = filt_index != nullptr;
+    if (binned) {
+        SPH3D_REQUIRE(n > 2 && n % 2 == 0, "Need n_>2 and n_%%2==0, got %d", n);               // tf_buildkernel.cpp:43
+        SPH3D_REQUIRE(p > 0 && p % 2 == 0, "Need p_>0 and p_%%2==0, got %d", p);               // :46
+        SPH3D_REQUIRE(q > 0, "Need q_>0, got %d", q);                                          // :49
+    } else {
+        SPH3D_REQUIRE(transpose_workspace != nullptr, "build_sphere_graph: without bins the call must count (workspace)");
+    }
+    const int F = binned ? n * p * q + 1 : 1;
     GraphFuse fx{};
     fx.n = n; fx.p = p; fx.q = q; fx.F = F;
     fx.radius = radius;
@@ -446,9 +452,9 @@ extern "C" int sph3d_build_sphere_graph(int B, int N, int M, int nn_sample, floa
     int rc = sphere_neighbor(0, B, N, M, nn_sample, radius, database, query, nn_index, nn_count, nn_dist, stream, &fx, &fused);
     if (rc || fused) return rc;
     // shapes whose hit lists do not fit LDS: the same results from the separate kernels
-    rc = sph3d_spherical_kernel(B, N, M, nn_sample, n, p, q, radius, database, query, nn_index, nn_count, nn_dist, filt_index, stream);
+    if (binned) rc = sph3d_spherical_kernel(B, N, M, nn_sample, n, p, q, radius, database, query, nn_index, nn_count, nn_dist, filt_index, stream);
     if (rc || transpose_workspace == nullptr) return rc;
-    return sph3d_graph_transpose_count(B, N, M, nn_sample, F, nn_index, nn_count, filt_index, 1, transpose_workspace,
+    return sph3d_graph_transpose_count(B, N, M, nn_sample, F, nn_index, nn_count, filt_index, binned ? 1 : 0, transpose_workspace,
                                        transpose_workspace_bytes, stream);
 }
 

@@ -149,3 +149,31 @@ def build_sphere_graph(xyz, radius, nnsample, kernel, with_transpose=True):
     if with_transpose:
         _tgraph.transpose(nn_index, nn_count, N, bin_index=filt, num_bins=F, counted_workspace=ws)
     return nn_index, nn_count, nn_dist, filt
+
+
+def build_sphere_neighbor_counted(database, query, radius, nnsample):
+    """build_sphere_neighbor(database, query, radius, None, nnsample) whose kernel also counts the in-edges of every
+    database point, i.e. runs the first pass of the transposed graph that the un-pooling gradient gathers over
+    (tf_unpool3d: mean interpolation); the transpose is finished and cached here.  Same three tensors, bit for bit.
+    -> nn_index, nn_count, nn_dist"""
+    from . import _tgraph
+    database = _lib.f32(database[:, :, 0:3])
+    query = _lib.f32(query[:, :, 0:3])
+    _lib.require_device(database, query)
+    if _radius_mode == "fixed":
+        raise ValueError("build_sphere_neighbor_counted implements the reference (compat) radius semantics only")
+    B, N, _ = database.shape
+    M = query.shape[1]
+    K = int(nnsample)
+    dev = database.device
+    nn_index = torch.empty((B, M, K), dtype=torch.int32, device=dev)
+    nn_count = torch.empty((B, M), dtype=torch.int32, device=dev)
+    nn_dist = torch.empty((B, M, K), dtype=torch.float32, device=dev)
+    l = _lib.lib()
+    wsb = l.sph3d_graph_transpose_workspace(B, N, M, K, 1)
+    ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
+    _lib.check(l.sph3d_build_sphere_graph(B, N, M, K, float(radius), 0, 0, 0, _lib.ptr(database), _lib.ptr(query),
+                                          _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(nn_dist), _lib.ptr(None), _lib.ptr(ws), wsb,
+                                          _lib.stream_ptr()))
+    _tgraph.transpose(nn_index, nn_count, N, counted_workspace=ws)
+    return nn_index, nn_count, nn_dist

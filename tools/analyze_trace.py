@@ -3,7 +3,7 @@ queue, and for every kernel of that queue how much of its duration overlapped ke
 usage: python tools/analyze_trace.py <kernel_trace.csv> [first_step_fraction_to_skip]"""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
-ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), r["Kernel_Name"]) for r in rows]
+ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), r["Kernel_Name"], int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) // max(1, int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]))) for r in rows]
 ev.sort()
 # steady-state window: one fps_reg_kernel<8> launch per training step; steps 20..28 of the run lie inside bench.py's
 # timed region (16 priming + 2 warm-up steps come first)
@@ -18,17 +18,17 @@ print("window %.2f ms = %d steps of %.2f ms, %d kernels" % (span, nsteps, span /
 busy = {}
 for q, l in byq.items():
     b = 0; end = 0
-    for s, e, _, _ in l:
+    for s, e, *_ in l:
         if e > end: b += e - max(s, end); end = e
     busy[q] = b / 1e6
-    print("queue %d: %5d kernels, busy %.2f ms (%.0f %% of the window), sum of durations %.2f ms" % (q, len(l), busy[q], 100 * busy[q] / span, sum(e - s for s, e, _, _ in l) / 1e6))
+    print("queue %d: %5d kernels, busy %.2f ms (%.0f %% of the window), sum of durations %.2f ms" % (q, len(l), busy[q], 100 * busy[q] / span, sum(x[1] - x[0] for x in l) / 1e6))
 main = max(busy, key=lambda q: len(byq[q]))
 l = byq[main]
 gaps = [l[i + 1][0] - max(x[1] for x in l[:i + 1][-4:]) for i in range(len(l) - 1)]
 gaps = [g for g in gaps if g > 0]
 print("main queue %d: idle between kernels %.2f ms in %d gaps (median %.1f us, >20 us: %d gaps = %.2f ms)" % (
     main, sum(gaps) / 1e6, len(gaps), sorted(gaps)[len(gaps) // 2] / 1e3, sum(1 for g in gaps if g > 20000), sum(g for g in gaps if g > 20000) / 1e6))
-others = sorted((s, e) for q, ll in byq.items() if q != main for s, e, _, _ in ll)
+others = sorted((x[0], x[1]) for q, ll in byq.items() if q != main for x in ll)
 def overlap(s, e):
     o = 0
     for a, b in others:
@@ -38,7 +38,7 @@ def overlap(s, e):
 agg = collections.defaultdict(lambda: [0, 0, 0, 0])
 import bisect
 starts = [a for a, b in others]
-for s, e, _, name in l:
+for s, e, _, name, _wg in l:
     i = max(0, bisect.bisect_left(starts, s) - 64)
     o = 0
     for a, b in others[i:]:
@@ -52,9 +52,16 @@ for k, a in sorted(agg.items(), key=lambda x: -x[1][1])[:22]:
 for q, ll in byq.items():
     if q == main: continue
     agg2 = collections.defaultdict(lambda: [0, 0])
-    for s, e, _, name in ll:
+    for s, e, _, name, _wg in ll:
         k = name.split("(")[0][-60:]
         agg2[k][0] += 1; agg2[k][1] += e - s
     print("side queue %d, per step:" % q)
     for k, a in sorted(agg2.items(), key=lambda x: -x[1][1])[:12]:
         print("  %-62s %5.1f calls %6.3f ms" % (k, a[0] / nsteps, a[1] / 1e6 / nsteps))
+
+print("main-queue kernel time per step by launch size (workgroups):")
+bk = collections.OrderedDict((k, [0, 0]) for k in ("<=16", "17-64", "65-255", "256-1023", ">=1024"))
+for s_, e_, _, name, wg in l:
+    k = "<=16" if wg <= 16 else "17-64" if wg <= 64 else "65-255" if wg < 256 else "256-1023" if wg < 1024 else ">=1024"
+    bk[k][0] += 1; bk[k][1] += e_ - s_
+for k, a in bk.items(): print("  %-9s %6.1f launches %6.3f ms" % (k, a[0] / nsteps, a[1] / 1e6 / nsteps))
