@@ -421,6 +421,8 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
     // static interleave leaves the busiest wave of an XCD with 1.4x the mean number of in-edges — the in-degree is
     // heavy-tailed: level 0 mean 48, sigma 45, max 537, tools/exp_bwd_balance.py — but with tickets of 4 or 8 positions
     // the level-0 kernels ran 0.66 / 0.55 ms against 0.53 / 0.35 ms, with or without waiting for the atomic at once.)
+    // (Also dropped: the four waves of a workgroup taking the workgroup's positions from an LDS counter — the extra live
+    // scalars of the flattened (item, position) loop pushed the kernel from 119 VGPRs to 128 + 232 B of scratch: 1.16 ms.)
     for (int item = xcd; item < B * parts; item += 8) {
     const int b = item / parts;
     const int pi = item - b * parts;
