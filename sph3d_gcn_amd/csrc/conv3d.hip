@@ -612,8 +612,20 @@ __global__ __launch_bounds__(1024) void reduce_filter_partials(int nparts, int t
     const int cx = (int)threadIdx.x & 31, py = (int)threadIdx.x >> 5;
     const int j = blockIdx.x * 32 + cx;
     float s = 0.f;
-    if (j < total)
-        for (int p = py; p < nparts; p += 32) s += partial[(size_t)p * total + j];
+    if (j < total) {
+        // eight slabs per trip, loads issued together (one per trip = up to 32 dependent L2 round trips per launch)
+        for (int p0 = py; p0 < nparts; p0 += 256) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int p = p0 + u * 32;
+                v[u] = partial[(size_t)(p < nparts ? p : py) * total + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (p0 + u * 32 < nparts) s += v[u];
+        }
+    }
     red[py][cx] = s;
     __syncthreads();
     if (py == 0 && j < total) {
