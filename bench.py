@@ -122,35 +122,6 @@ def train_step(model, flat, opt, pts, label, inner):
     return loss
 
 
-class GraphedStep:
-    """The step's device work (graph construction + forward + backward: ~600 launches on two streams) captured
-    once into a HIP graph and replayed: the eager step is launch-bound on the host (Python op dispatch), the
-    replay is not.  Gradient all-reduce and the optimiser update stay outside the graph."""
-
-    def __init__(self, model, flat, pts, label, inner):
-        from sph3d_gcn_amd import _tgraph
-        self.flat = flat
-        self.graph = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                 # PyTorch's capture recipe: warm up on a side stream
-            for _ in range(2):
-                fwd_bwd(model, flat, pts, label, inner)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        _tgraph.clear()
-        with torch.cuda.graph(self.graph):
-            self.loss = fwd_bwd(model, flat, pts, label, inner)
-        _tgraph.clear()
-        torch.cuda.synchronize()
-
-    def step(self, opt):
-        self.graph.replay()
-        self.flat.all_reduce()
-        opt.step()
-        return self.loss
-
-
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -298,7 +269,6 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--hipgraph", action="store_true", help="capture fwd+bwd into a HIP graph and replay it (experimental)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -334,20 +304,11 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # (launch mode: eager on three HIP streams.  A HIP-graph replay of the step was tried in round 1 and removed in round 2:
+    #  capturing the three-stream step does not complete on this stack — DESIGN.md section 5)
     mode = "eager"
-    graphed = None
-    if args.hipgraph:
-        try:
-            graphed = GraphedStep(model, flat, pts, label, inner)
-            mode = "hipgraph"
-        except Exception as e:      # capture is an optimisation, never a requirement
-            sys.stderr.write("HIP graph capture failed (%s: %s); running eagerly\n" % (type(e).__name__, e))
-            graphed = None
-            torch.cuda.synchronize()
 
     def one_step():
-        if graphed is not None:
-            return graphed.step(opt)
         p_, l_, i_ = batches[step_no[0] % NUM_BATCHES]        # a different resident batch every step
         step_no[0] += 1
         return train_step(model, flat, opt, p_, l_, i_)
