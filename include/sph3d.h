@@ -158,6 +158,11 @@ int sph3d_graph_transpose_finish(int B, int N, int M, int K, int F,
                                  const int* nn_index, const int* nn_count, const int* bin_index,
                                  const float* weight, int* offsets, int* ent_key, float* ent_scale, int* active_bins,
                                  void* workspace, size_t workspace_bytes, sph3d_stream_t stream);
+/* A processing order for sph3d_depthwise_conv3d_grad_t (its source_order argument) that balances the in-edges over the
+ * gradient kernel's waves: inside windows of 2048 consecutive source points the points are sorted by in-degree (read from
+ * `offsets` of the transposed graph with F bins), alternately descending and ascending.  order[B*N], a permutation per
+ * cloud; results of the gradient are the same sums in a different order of the filter-gradient partials. */
+int sph3d_graph_balanced_order(int B, int N, int F, const int* offsets, int* order, sph3d_stream_t stream);
 /* conv gradients from a prebuilt transposed graph: both gradients in one pass, no float atomics
  * (grad_input gathered in registers; grad_filter accumulated in per-lane registers by persistent workgroups
  * that sweep the clouds of their XCD, one partial table per workgroup written to `workspace` =

@@ -12,6 +12,7 @@ import torch
 
 from . import _lib
 
+BALANCE_MIN_POINTS = 1024   # binned graphs with at least this many source points get a degree-balanced gradient order
 _MAX_ENTRIES = 16      # one S3DIS step builds 12 (8 binned intra graphs + 4 inter graphs); entries pin ~150 MB each at level 0
 _cache = collections.OrderedDict()
 
@@ -38,7 +39,12 @@ def set_source_order(nn_index, order):
 
 def source_order(nn_index):
     hit = _orders.get(_ident(nn_index))
-    return None if hit is None else hit[0]
+    if hit is None:
+        return None
+    order = hit[0]
+    if order.is_cuda:
+        order.record_stream(torch.cuda.current_stream())      # built on the graph stream, read by this stream's kernels
+    return order
 
 
 def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1, counted_workspace=None):
@@ -77,6 +83,12 @@ def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1
         _lib.check(l.sph3d_graph_transpose(B, n_src, M, K, F, _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(bin_index),
                                            _lib.ptr(weight), _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale),
                                            _lib.ptr(active), _lib.ptr(ws), wsb, _lib.stream_ptr()))
+    if bin_index is not None and n_src >= BALANCE_MIN_POINTS and _ident(nn_index) not in _orders:
+        # processing order of the convolution gradient that evens out the in-edges per wave (sph3d_graph_balanced_order);
+        # an order registered by the caller (set_source_order) wins
+        order = torch.empty((B, n_src), dtype=torch.int32, device=dev)
+        _lib.check(l.sph3d_graph_balanced_order(B, n_src, F, _lib.ptr(offsets), _lib.ptr(order), _lib.stream_ptr()))
+        set_source_order(nn_index, order)
     out = (offsets, ent_key, ent_scale, active)
     ev = torch.cuda.Event()
     ev.record(cur)

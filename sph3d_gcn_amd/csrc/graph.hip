@@ -254,6 +254,60 @@ extern "C" int sph3d_graph_transpose_finish(int B, int N, int M, int K, int F,
     return check_launch("sph3d_graph_transpose");
 }
 
+// Degree-balanced processing order for the convolution gradient.  Its persistent workgroups deal a cloud's source points to
+// their waves position by position (wave g takes positions g, g + stride, ...), and the in-degree of the sources is
+// heavy-tailed (S3DIS level 0: mean 48, sigma 45, max 537: the first-K rule favours low indices), so in index order the
+// busiest wave of an XCD gets 1.4x the mean number of edges.  Inside every window of 2048 consecutive sources this kernel
+// sorts the sources by in-degree — descending in even windows, ascending in odd ones — so that the positions a wave visits
+// run through all the degree quantiles: level-0 gradient 0.53 -> 0.46 ms (C = 128), 0.36 -> 0.31 ms (C = 64).
+// One workgroup per (window, cloud): bitonic sort of unique keys (degree, local index) in LDS — deterministic.
+constexpr int kOrderWindow = 2048;
+__global__ __launch_bounds__(1024) void tg_balanced_order(int N, int F, const int* __restrict__ offsets, int* __restrict__ order)
+{
+    __shared__ unsigned keys[kOrderWindow];
+    const int win = (int)blockIdx.x, b = (int)blockIdx.y;
+    const int base = win * kOrderWindow;
+    const int cnt = (N - base) < kOrderWindow ? (N - base) : kOrderWindow;
+    const int* __restrict__ ob = offsets + (size_t)b * ((size_t)N * F + 1);
+    for (int i = (int)threadIdx.x; i < kOrderWindow; i += 1024) {
+        unsigned k = 0xffffffffu;                                  // padding sorts to the end
+        if (i < cnt) {
+            const size_t n = (size_t)(base + i);
+            int deg = ob[(n + 1) * F] - ob[n * F];
+            deg = deg < (1 << 20) ? deg : (1 << 20);
+            k = ((unsigned)deg << 11) | (unsigned)i;
+        }
+        keys[i] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= kOrderWindow; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = (int)threadIdx.x; i < kOrderWindow; i += 1024) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned a = keys[i], c = keys[p];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) { keys[i] = c; keys[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = (int)threadIdx.x; i < cnt; i += 1024) {
+        const int src = (win & 1) ? i : (cnt - 1 - i);              // even windows: heaviest first
+        order[(size_t)b * N + base + i] = base + (int)(keys[src] & 2047u);
+    }
+}
+
+extern "C" int sph3d_graph_balanced_order(int B, int N, int F, const int* offsets, int* order, sph3d_stream_t stream)
+{
+    SPH3D_REQUIRE(B >= 0 && N > 0 && F > 0, "graph_balanced_order: bad dims B=%d N=%d F=%d", B, N, F);
+    if (B == 0) return SPH3D_OK;
+    hipLaunchKernelGGL(tg_balanced_order, dim3((N + kOrderWindow - 1) / kOrderWindow, B), dim3(1024), 0, as_stream(stream), N, F,
+                       offsets, order);
+    return check_launch("sph3d_graph_balanced_order");
+}
+
 // tf.gather_nd for (cloud, point) index pairs: out[b, s, :] = params[pair.b, pair.p, :] for rows of `row` 4-byte elements
 // (coordinates, neighbour lists, counts: models/SPH3D_s3dis.py:68-72 gathers the sampled points' rows this way).
 // One launch instead of two int32 -> int64 conversions plus an advanced-indexing kernel per tensor.

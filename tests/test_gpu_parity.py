@@ -741,3 +741,45 @@ def test_counted_inter_level_search_equals_separate_calls(dev):
         for n in range(0, N, 37):
             a, e = int(off[b, n]), int(off[b, n + 1])
             assert sorted(zip(k0[a:e].tolist(), s0[a:e].tolist())) == sorted(zip(k1[a:e].tolist(), s1[a:e].tolist()))
+
+
+@pytest.mark.gpu
+def test_balanced_gradient_order_is_a_permutation_and_changes_nothing(dev):
+    """sph3d_graph_balanced_order: a permutation of every cloud, sorted by in-degree inside 2048-point windows (descending in
+    even windows, ascending in odd ones); the convolution gradient with it = the gradient in index order (same per-source sums;
+    the filter gradient only re-associates its partial sums)"""
+    from sph3d_gcn_amd import tf_nnquery, tf_buildkernel, tf_conv3d, _tgraph, _lib
+    g = torch.Generator().manual_seed(5)
+    B, N, K, C = 2, 5000, 32, 64
+    xyz = torch.rand((B, N, 3), generator=g).to(dev)
+    idx, cnt, dst = tf_nnquery.build_sphere_neighbor(xyz, xyz, 0.08, None, K)
+    filt = tf_buildkernel.spherical_kernel(xyz, xyz, idx, cnt, dst, 0.08, [8, 2, 2])
+    x = torch.randn((B, N, C), generator=g).to(dev); w = torch.randn((33, C, 2), generator=g).to(dev)
+    go = torch.randn((B, N, 2 * C), generator=g).to(dev)
+    _tgraph.clear()
+    old = _tgraph.BALANCE_MIN_POINTS
+    try:
+        _tgraph.BALANCE_MIN_POINTS = 1 << 30
+        gi0, gf0 = tf_conv3d.depthwise_conv3d_grad(x, w, go, idx, cnt, filt)
+        assert _tgraph.source_order(idx) is None
+        _tgraph.clear()
+        _tgraph.BALANCE_MIN_POINTS = 1024
+        gi1, gf1 = tf_conv3d.depthwise_conv3d_grad(x, w, go, idx, cnt, filt)
+    finally:
+        _tgraph.BALANCE_MIN_POINTS = old
+    order = _tgraph.source_order(idx)
+    assert order is not None and order.shape == (B, N)
+    o = order.cpu().long()
+    off = _tgraph.transpose(idx, cnt, N, bin_index=filt, num_bins=33)[0].view(B, N * 33 + 1).cpu().long()
+    for b in range(B):
+        assert torch.equal(torch.sort(o[b]).values, torch.arange(N))
+        deg = off[b, 33::33] - off[b, 0:-1:33]
+        for wi, lo in enumerate(range(0, N, 2048)):
+            win = o[b, lo:lo + 2048]
+            assert int(win.min()) >= lo and int(win.max()) < min(lo + 2048, N)
+            d = deg[win]
+            assert bool((d[1:] >= d[:-1]).all()) if wi % 2 else bool((d[1:] <= d[:-1]).all())
+    # (the two transposed graphs were built separately: entries inside a (source, bin) segment land in atomic-arrival order,
+    # so even the per-source sums may re-associate)
+    assert float((gi0 - gi1).abs().max()) <= 1e-5 * float(gi0.abs().max())
+    assert float((gf0 - gf1).abs().max()) <= 1e-5 * float(gf0.abs().max())
