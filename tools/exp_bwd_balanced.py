@@ -31,10 +31,13 @@ t_ord = timeit(lambda: balanced_order(512))
 for C in (128, 64):
     x = torch.randn(B, N, C, device=dev); w = torch.randn(33, C, 2, device=dev); go = torch.randn(B, N, C * 2, device=dev)
     res = []
-    for win in (0, 512, 1024, 2048):
+    builtin = torch.empty((B, N), dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().sph3d_graph_balanced_order(B, N, 33, _lib.ptr(offsets), _lib.ptr(builtin), _lib.stream_ptr()))
+    for win in (0, 512, 1024, 2048, -1):
         _tgraph._orders.clear()
-        if win: _tgraph.set_source_order(nidx, balanced_order(win))
+        if win > 0: _tgraph.set_source_order(nidx, balanced_order(win))
+        if win < 0: _tgraph.set_source_order(nidx, builtin)
         gi, gf = tf_conv3d.depthwise_conv3d_grad(x, w, go, nidx, cnt, filt)
         res.append((win, timeit(lambda: tf_conv3d.depthwise_conv3d_grad(x, w, go, nidx, cnt, filt)), gi, gf))
     d = max(float((res[0][2] - r[2]).abs().max()) for r in res[1:])
-    print("C=%d: " % C + "  ".join("%s %.3f ms" % ("index order" if w_ == 0 else "window %d" % w_, t) for w_, t, _, _ in res) + "  (max diff %.1e; order by torch ops %.3f ms)" % (d, t_ord), flush=True)
+    print("C=%d: " % C + "  ".join("%s %.3f ms" % ("index order" if w_ == 0 else ("built-in" if w_ < 0 else "window %d" % w_), t) for w_, t, _, _ in res) + "  (max diff %.1e; order by torch ops %.3f ms)" % (d, t_ord), flush=True)
