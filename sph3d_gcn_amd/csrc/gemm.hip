@@ -30,6 +30,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 as_v4(const float4 v) { f32x4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
 
+#ifndef SPH3D_GEMM_SETPRIO
+#define SPH3D_GEMM_SETPRIO 1
+#endif
+constexpr bool kSetPrio = SPH3D_GEMM_SETPRIO != 0;
 constexpr int BM = 128;
 constexpr int BKS = 16;      // k-tile for small grids (more workgroups per CU)
 constexpr int BKL = 32;      // k-tile for large grids (half the barriers)
@@ -240,6 +244,7 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? 4 : 2) void gemm_f32_mf
         }
         const float* ca = lds + buf * BUF;
         const float* cb = ca + SA::LDS_FLOATS;
+        if (kSetPrio) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int g = 0; g < BK / 8; g++) {
             f32x4 af[TM], bf[TN];
@@ -259,6 +264,7 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? 4 : 2) void gemm_f32_mf
                     }
             }
         }
+        if (kSetPrio) __builtin_amdgcn_s_setprio(0);
         if (more) {                       // the other buffer: nobody reads it during this iteration
             sa.store(lds + (buf ^ 1) * BUF);
             sb.store(lds + (buf ^ 1) * BUF + SA::LDS_FLOATS);
