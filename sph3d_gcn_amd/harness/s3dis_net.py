@@ -183,9 +183,10 @@ class GraphPlan:
         xyz_c, xyz_unpool = self.xyz_layers[L - l], self.xyz_layers[L - 1 - l]     # = reversed(xyz_layers)[l], [l + 1]
         # build_graph_deconv (util.py:52-58) + spherical_kernel: the intra half fused, the inter search as is
         intra_idx, intra_cnt, intra_dst, filt_idx = s3g_util.build_intra_graph(xyz_c, radius, uplimit, c.kernel)
-        if xyz_c.is_cuda and c.unpool_method == 'mean' and s3g_util.neighbor_fn is s3g_util.build_sphere_neighbor:
+        from .. import tf_nnquery
+        if (xyz_c.is_cuda and c.unpool_method == 'mean' and s3g_util.neighbor_fn is s3g_util.build_sphere_neighbor
+                and tf_nnquery.get_radius_mode() == "compat"):
             # the search also counts the in-edges: first pass of the transposed graph of the un-pooling gradient
-            from .. import tf_nnquery
             inter_idx, inter_cnt, inter_dst = tf_nnquery.build_sphere_neighbor_counted(xyz_c, xyz_unpool, radius, uplimit)
         else:
             inter_idx, inter_cnt, inter_dst = s3g_util.neighbor_fn(xyz_c, xyz_unpool, radius=radius, nnsample=uplimit)

@@ -189,7 +189,7 @@ def build_intra_graph(xyz, radius, nn_uplimit, kernel):
     fused kernel on the HIP device (tf_nnquery.build_sphere_graph); on other tensors (the CPU-oracle-backed tests) the two
     calls are made one after the other.  -> nn_idx, nn_cnt, nn_dst, filt_idx"""
     from . import tf_nnquery
-    if xyz.is_cuda and neighbor_fn is build_sphere_neighbor:
+    if xyz.is_cuda and neighbor_fn is build_sphere_neighbor and tf_nnquery.get_radius_mode() == "compat":
         return tf_nnquery.build_sphere_graph(xyz, radius, nn_uplimit, kernel)
     idx, cnt, dst = neighbor_fn(xyz, xyz, radius=radius, nnsample=nn_uplimit)
     return idx, cnt, dst, spherical_kernel(xyz, xyz, idx, cnt, dst, radius, kernel=kernel)

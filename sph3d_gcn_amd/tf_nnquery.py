@@ -13,6 +13,10 @@ from . import _lib
 _radius_mode = "compat"
 
 
+def get_radius_mode():
+    return _radius_mode
+
+
 def set_radius_mode(mode):
     """"compat" (default): the reference's semantics, bit-exact — the radius a reference thread grew is carried to the next
     query of its chain (tf_nnquery_gpu.cu:59).  "fixed": every query is searched with the nominal radius (growth only until

@@ -194,3 +194,25 @@ def test_scannet_65536_fixed_radius_mode(dev):
     io, co, do = oracle.build_sphere_neighbor(xyz, xyz[:, :512], r, None, K, fixed=True)
     fo = oracle.spherical_kernel(xyz, xyz[:, :512], io, co, do, r, [8, 2, 2])
     np.testing.assert_allclose(_n(out)[:, :512], oracle.depthwise_conv3d(_n(x), _n(w), io, co, fo), **TOL)
+
+
+@pytest.mark.gpu
+def test_fixed_radius_mode_runs_the_model_graph_through_the_plain_kernels():
+    """in the labelled non-reference radius mode the fused graph kernels (reference semantics only) must not be chosen: the
+    model graph falls back to the separate search / binning ops and still steps"""
+    import torch
+    from sph3d_gcn_amd import tf_nnquery
+    from sph3d_gcn_amd.harness import s3dis_net, synth
+    dev = torch.device("cuda:0")
+    cfg = s3dis_net.small_config(1024)
+    xyz, label, inner = synth.s3dis_batch(3, 2, 1024, extent=(1.0, 1.0, 1.5))
+    pts = torch.from_numpy(xyz).to(dev); label = torch.from_numpy(label).to(dev); inner = torch.from_numpy(inner).to(dev)
+    tf_nnquery.set_radius_mode("fixed")
+    try:
+        model = s3dis_net.SPH3DS3DIS(cfg, device=dev)
+        pred, _ = model(pts, True)
+        loss = model.loss(pred, label, inner)
+        loss.backward()
+        assert torch.isfinite(loss).item()
+    finally:
+        tf_nnquery.set_radius_mode("compat")
