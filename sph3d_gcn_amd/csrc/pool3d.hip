@@ -48,7 +48,10 @@ __global__ __launch_bounds__(256) void gather_fwd(
             int arg[V];
 #pragma unroll
             for (int v = 0; v < V; v++) { acc[v] = 0.f; arg[v] = 0; }
-            const int* __restrict__ irow = nnIndex + row * K;   // wave-uniform address -> scalar loads
+            // wave-uniform address -> scalar loads, eight consecutive ids per s_load_dwordx8.  (Round 2: the vector-load +
+            // v_readlane scheme that helped the convolution gradient made the step 3.7 % SLOWER here: these loops have no
+            // clamps or interleaved scale loads for it to remove, and a readlane per edge costs more than an eighth of a wide s_load.)
+            const int* __restrict__ irow = nnIndex + row * K;
             const float* __restrict__ wrow = weight + row * K;
             {
 #pragma unroll 8
