@@ -456,6 +456,15 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
         // trip per batch of four edges.
         const int E0 = __builtin_amdgcn_readlane(ov0, 0);
         const int E1 = uniform(o[F]);
+        // COMPACT: which accumulator rows have a non-empty segment at this source (about half of the 17 do not): one mask per
+        // source instead of two v_readlane + clamps + compare per empty segment
+        unsigned long long nonempty = ~0ull;
+        if (COMPACT) {
+            const int fl = lane < MAXF ? abv : 0;
+            const int s0 = __builtin_amdgcn_ds_bpermute(fl << 2, ov0);
+            const int s1 = __builtin_amdgcn_ds_bpermute((fl + 1) << 2, ov0);
+            nonempty = __ballot(s1 > s0);
+        }
         for (int cb = E0; cb < E1; cb += 64) {
         const int cn = (E1 - cb) < 64 ? (E1 - cb) : 64;
         const int li = lane < cn ? lane : 0;
@@ -464,7 +473,7 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
         const float sv = lane < cn ? svl : 0.f;
 #pragma unroll
         for (int fi = 0; fi < MAXF; fi++) {
-            if (fi < (COMPACT ? A : F)) {
+            if (fi < (COMPACT ? A : F) && ((nonempty >> fi) & 1ull)) {
                 // COMPACT: row fi of the accumulators belongs to bin activeBins[1 + fi] (wave-uniform, F <= 63)
                 const int f = COMPACT ? __builtin_amdgcn_readlane(abv, fi) : fi;
                 const int a0 = COMPACT ? __builtin_amdgcn_readlane(ov0, f)
