@@ -487,6 +487,13 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
                     float sg[V];
 #pragma unroll
                     for (int v = 0; v < V; v++) sg[v] = 0.f;
+                    // the segment's filter row is read from LDS now, under the gathers, not after them
+                    float wr[V];
+                    {
+                        const float* wrow = &lfilt[f * SL + (act ? cl0 : 0)];
+#pragma unroll
+                        for (int v = 0; v < V; v++) wr[v] = wrow[v];
+                    }
                     if (HALF) {
                         // the two half-waves take alternate edges: lane-half h reads edge e + 2u + h of the chunk through
                         // ds_bpermute (lane number modulo 64, scales masked to the segment: see the full-wave branch)
@@ -543,10 +550,9 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
                             for (int v = 0; v < V; v++) sg[v] = fmaf(g[u][v], sc[u], sg[v]);
                     }
                     }
-                    const float* wrow = &lfilt[f * SL + (act ? cl0 : 0)];
 #pragma unroll
                     for (int v = 0; v < V; v++) {
-                        gi[v] = fmaf(sg[v], wrow[v], gi[v]);
+                        gi[v] = fmaf(sg[v], wr[v], gi[v]);
                         acc[fi][v] = fmaf(sg[v], xv[v], acc[fi][v]);
                     }
                 }
