@@ -186,6 +186,9 @@ __global__ __launch_bounds__(256) void dwconv_fwd_row(
         const int cl = e - f * SL;
         *reinterpret_cast<float4*>(&lfilt[e]) = *reinterpret_cast<const float4*>(&filter[(size_t)f * CR + slice0 + cl]);
     }
+    // row F: all zeros — the filter row of padding slots (batches of eight run past the neighbour count without clamps or
+    // conditional FMAs: a padding slot multiplies the row's FIRST neighbour by exactly 0)
+    for (int e = threadIdx.x; e < SL; e += blockDim.x) lfilt[F * SL + e] = 0.f;
     __syncthreads();
 
     const int wave = uniform((int)threadIdx.x >> 6);
@@ -210,19 +213,25 @@ __global__ __launch_bounds__(256) void dwconv_fwd_row(
         for (int kt = 0; kt < cnt; kt += 64) {
             // the row's neighbour ids and bin ids: ONE coalesced 256-B read each (lane k holds slot kt + k) ...
             const int myk = kt + lane;
-            const int idxv = myk < cnt ? nnIndex[row * K + myk] : 0;
-            int binv = myk < cnt ? binIndex[row * K + myk] : 0;
-            binv = binv < 0 ? 0 : (binv >= F ? F - 1 : binv);     // out-of-range bin ids: same clamp as the transposed graph
             const int kn = (cnt - kt) < 64 ? (cnt - kt) : 64;
+            const int mykc = myk < cnt ? myk : kt;                 // padding lanes: the chunk's first neighbour (a real one) ...
+            const int idxv = nnIndex[row * K + mykc];
+            int binv = binIndex[row * K + mykc];
+            binv = binv < 0 ? 0 : (binv >= F ? F - 1 : binv);     // out-of-range bin ids: same clamp as the transposed graph
+            binv = myk < cnt ? binv : F;                           // ... times the zero row
+            // element offsets of the input row and of the filter row, once per 64 edges (N * C < 2^32: checked by the launcher)
+            const unsigned noff = (unsigned)idxv * (unsigned)C;
+            const int foff = binv * (SL >> 2);                     // in float4 units: keeps the LDS read a 16-byte aligned ds_read_b128
             // ... then consumed eight at a time: 8 lane->scalar broadcasts, 8 independent row gathers and 8 filter
-            // reads are in flight before the first FMA (the kernel is latency-bound otherwise)
+            // reads are in flight before the first FMA (the kernel is latency-bound otherwise).  kBatch divides 64, so
+            // k8 + u <= 63: no clamp
             for (int k8 = 0; k8 < kn; k8 += kBatch) {
-                int n[kBatch], f[kBatch];
+                unsigned n[kBatch];
+                int f[kBatch];
 #pragma unroll
                 for (int u = 0; u < kBatch; u++) {
-                    const int kk = (k8 + u) < kn ? (k8 + u) : (kn - 1);
-                    n[u] = __builtin_amdgcn_readlane(idxv, kk);
-                    f[u] = __builtin_amdgcn_readlane(binv, kk);
+                    n[u] = (unsigned)__builtin_amdgcn_readlane((int)noff, k8 + u);
+                    f[u] = __builtin_amdgcn_readlane(foff, k8 + u);
                 }
                 float4 w[kBatch];
                 float4 x[kBatch];
@@ -230,22 +239,21 @@ __global__ __launch_bounds__(256) void dwconv_fwd_row(
                 for (int u = 0; u < kBatch; u++) {
                     // no per-lane branch here: inactive lanes (slices narrower than 256) read lane 0's columns, so the
                     // eight loads stay in one basic block and are all in flight together
-                    w[u] = *reinterpret_cast<const float4*>(&lfilt[f[u] * SL + clc]);
+                    w[u] = reinterpret_cast<const float4*>(lfilt)[f[u] + (clc >> 2)];
+                    const float* __restrict__ rp = inb + n[u];          // wave-uniform row address (scalar registers)
                     if (R == 2) {
-                        const float2 t = *reinterpret_cast<const float2*>(&inb[(size_t)n[u] * C + cinc]);
+                        const float2 t = *reinterpret_cast<const float2*>(&rp[(unsigned)cinc]);
                         x[u] = make_float4(t.x, t.x, t.y, t.y);
                     } else {
-                        x[u] = *reinterpret_cast<const float4*>(&inb[(size_t)n[u] * C + cinc]);
+                        x[u] = *reinterpret_cast<const float4*>(&rp[(unsigned)cinc]);
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < kBatch; u++) {
-                    if ((k8 + u) < kn) {      // wave-uniform: padding slots of the last batch are skipped
-                        acc.x = fmaf(x[u].x, w[u].x, acc.x);
-                        acc.y = fmaf(x[u].y, w[u].y, acc.y);
-                        acc.z = fmaf(x[u].z, w[u].z, acc.z);
-                        acc.w = fmaf(x[u].w, w[u].w, acc.w);
-                    }
+                    acc.x = fmaf(x[u].x, w[u].x, acc.x);
+                    acc.y = fmaf(x[u].y, w[u].y, acc.y);
+                    acc.z = fmaf(x[u].z, w[u].z, acc.z);
+                    acc.w = fmaf(x[u].w, w[u].w, acc.w);
                 }
             }
         }
@@ -754,10 +762,10 @@ extern "C" int sph3d_depthwise_conv3d(int B, int N, int M, int F, int C, int r, 
             hipLaunchKernelGGL((dwconv_fwd_multi<1, 16, kFwdSB>), grid, dim3(256), lds, st, B, N, M, F, C, K, mblocks,
                                nslices, nn_index, nn_count, bin_index, input, filter, output);
         }
-    } else if (vec) {
+    } else if (vec && (unsigned long long)N * C + 256ull < (1ull << 32)) {       // (32-bit row offsets in the kernel)
         const int nslices = (CR + kSlice - 1) / kSlice;
         const int SLmax = CR < kSlice ? CR : kSlice;
-        const size_t lds = (size_t)F * SLmax * sizeof(float);
+        const size_t lds = (size_t)(F + 1) * SLmax * sizeof(float);      // + the zero row of the padding slots
         const dim3 grid(xcd_grid(B, mblocks * nslices));
         if (r == 2) {
             SPH3D_BIG_LDS(dwconv_fwd_row<2>)
