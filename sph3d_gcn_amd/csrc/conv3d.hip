@@ -74,6 +74,8 @@ __global__ __launch_bounds__(256) void dwconv_fwd_multi(
         *reinterpret_cast<float4*>(&lfilt[f * SLo + q * SLi + l4 * 4]) =
             *reinterpret_cast<const float4*>(&filter[(size_t)f * CR + ci0 * R + cl]);
     }
+    // row F: all zeros, the filter row of padding slots (see dwconv_fwd_row)
+    for (int e = threadIdx.x; e < SLo; e += blockDim.x) lfilt[F * SLo + e] = 0.f;
     __syncthreads();
 
     const int wave = uniform((int)threadIdx.x >> 6);
@@ -85,7 +87,6 @@ __global__ __launch_bounds__(256) void dwconv_fwd_multi(
     const int m_begin = mb * kFwdPointsPerWG;
     const int m_end = (m_begin + kFwdPointsPerWG) < M ? (m_begin + kFwdPointsPerWG) : M;
     const float* inb = input + (size_t)b * N * C + ci0 + cic;
-    const float* lw = lfilt + cic;
 
     for (int m = m_begin + wave; m < m_end; m += 4) {
         const size_t row = (size_t)b * M + m;
@@ -96,10 +97,15 @@ __global__ __launch_bounds__(256) void dwconv_fwd_multi(
         for (int kt = 0; kt < cnt; kt += 64) {
             // the row's neighbour ids and bin ids: ONE coalesced 256-B read each (lane k holds slot kt + k) ...
             const int myk = kt + lane;
-            const int idxv = myk < cnt ? nnIndex[row * K + myk] : 0;
-            int binv = myk < cnt ? binIndex[row * K + myk] : 0;
-            binv = binv < 0 ? 0 : (binv >= F ? F - 1 : binv);     // out-of-range bin ids: same clamp as the transposed graph
             const int kn = (cnt - kt) < 64 ? (cnt - kt) : 64;
+            const int mykc = myk < cnt ? myk : kt;                 // padding lanes: the chunk's first neighbour times the zero row
+            const int idxv = nnIndex[row * K + mykc];
+            int binv = binIndex[row * K + mykc];
+            binv = binv < 0 ? 0 : (binv >= F ? F - 1 : binv);     // out-of-range bin ids: same clamp as the transposed graph
+            binv = myk < cnt ? binv : F;
+            const unsigned noff = (unsigned)idxv * (unsigned)C;    // element offsets, once per 64 edges (N * C < 2^32: launcher)
+            const int foff = binv * (SLo >> 2);                    // float4 units: the LDS reads stay 16-byte aligned
+            static_assert(64 % (SB * EPL) == 0, "batches must tile the 64-edge chunk (no index clamps)");
             // ... then consumed SB wave loads (SB*EPL edges) at a time: all their gathers are in flight before the
             // first FMA (the kernel is latency-bound otherwise)
             for (int k0 = 0; k0 < kn; k0 += SB * EPL) {
@@ -110,26 +116,17 @@ __global__ __launch_bounds__(256) void dwconv_fwd_multi(
                     // lane group g takes edge k0 + u*EPL + g.  Measured: ds_bpermute (0.145 ms at C = 64) beats EPL v_readlane
                     // broadcasts + per-lane selects (0.203 ms) — the selects and the per-lane address arithmetic cost more
                     // VALU time than the LDS round trip
-                    const int kq = k0 + u * EPL + g;
-                    const bool valid = kq < kn;
-                    const int kk = valid ? kq : (kn - 1);
-                    const int n = __shfl(idxv, kk);
-                    const int f = __shfl(binv, kk);
-                    // no per-lane branch: padding slots re-read a valid row and are zeroed, so the SB loads stay in
-                    // one basic block and are all in flight together
-                    float4 t = *reinterpret_cast<const float4*>(&inb[(size_t)n * C]);
-                    // the (clamped, always legal) read must stay unconditional: otherwise the compiler sinks it under `valid`
-                    // and every step becomes an exec-masked block with its own wait (measured 0.135 -> 0.129 ms)
-                    asm volatile("" : "+v"(t.x), "+v"(t.y), "+v"(t.z), "+v"(t.w));
-                    x[u] = valid ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-                    fo[u] = f * SLo;
+                    const int kq = k0 + u * EPL + g;               // <= 63: padding slots hold a real row and the zero filter row
+                    const unsigned n = (unsigned)__shfl((int)noff, kq);
+                    fo[u] = __shfl(foff, kq);
+                    x[u] = *reinterpret_cast<const float4*>(&inb[n]);
                 }
 #pragma unroll
                 for (int u = 0; u < SB; u++) {
                     const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
 #pragma unroll
                     for (int q = 0; q < R; q++) {
-                        const float4 w = *reinterpret_cast<const float4*>(&lw[fo[u] + q * SLi]);
+                        const float4 w = reinterpret_cast<const float4*>(lfilt)[fo[u] + ((q * SLi + cic) >> 2)];
                         // outputs 4q..4q+3 of this lane belong to input channels (4q + j) / R
                         acc[4 * q + 0] = fmaf(xs[(4 * q + 0) / R], w.x, acc[4 * q + 0]);
                         acc[4 * q + 1] = fmaf(xs[(4 * q + 1) / R], w.y, acc[4 * q + 1]);
@@ -747,11 +744,11 @@ extern "C" int sph3d_depthwise_conv3d(int B, int N, int M, int F, int C, int r, 
                        "conv3d: hipFuncSetAttribute");                                                            \
         if (rc) return rc;                                                                                        \
     }
-    if (vec && C <= 64) {
+    if (vec && C <= 64 && (unsigned long long)N * C + 256ull < (1ull << 32)) {
         // narrow layers: 16 lanes per edge, four neighbour rows per wave load (measured at C = 64, r = 2: 0.254 -> 0.145 ms;
         // at C >= 128 the one-edge-per-load kernel below is faster: 0.297 vs 0.353 ms with two edges per load)
         const int nslices = 1;
-        const size_t lds = (size_t)F * C * r * sizeof(float);
+        const size_t lds = (size_t)(F + 1) * C * r * sizeof(float);      // + the zero row of the padding slots
         const dim3 grid(xcd_grid(B, mblocks * nslices));
         if (r == 2) {
             SPH3D_BIG_LDS((dwconv_fwd_multi<2, 16, kFwdSB>))
