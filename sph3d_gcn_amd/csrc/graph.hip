@@ -143,28 +143,33 @@ __global__ __launch_bounds__(256) void tg_active_bins(int F, const int* __restri
     if (threadIdx.x == 0) active[0] = run;
 }
 
+// one wave per graph row (b, m), lane = neighbour slot: no per-element 64-bit divisions, the row's count and 1/count
+// are wave-uniform, the id / bin / slot reads are coalesced 256-byte rows
 __global__ __launch_bounds__(256) void tg_fill(int B, int N, int M, int K, int F, const int* __restrict__ nnIndex,
                                                const int* __restrict__ nnCount, const int* __restrict__ binIndex,
                                                const float* __restrict__ weight, const int* __restrict__ offsets,
                                                const int* __restrict__ slotPos, int* __restrict__ entKey,
                                                float* __restrict__ entScale)
 {
-    const long long total = (long long)B * M * K;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const long long row = e / K;
-        const int k = (int)(e - row * K);
+    const int lane = (int)threadIdx.x & 63;
+    const long long nrows = (long long)B * M;
+    const long long wstride = (long long)gridDim.x * 4;
+    for (long long row = (long long)blockIdx.x * 4 + ((int)threadIdx.x >> 6); row < nrows; row += wstride) {
         const int cnt = nnCount[row];
-        if (k < cnt) {
-            const int b = (int)(row / M);
-            const int m = (int)(row - (long long)b * M);
+        if (cnt <= 0) continue;
+        const int b = (int)(row / M);                       // once per row
+        const int m = (int)(row - (long long)b * M);
+        const float inv = 1.0f / (float)cnt;
+        const int* __restrict__ ob = offsets + (size_t)b * ((size_t)N * F + 1);
+        const int lim = cnt < K ? cnt : K;
+        for (int k = lane; k < lim; k += 64) {
+            const long long e = row * K + k;
             const int n = nnIndex[e];
             int f = binIndex ? binIndex[e] : 0;
             f = f < 0 ? 0 : (f >= F ? F - 1 : f);
-            const size_t seg = (size_t)n * F + f;
-            const int dst = offsets[(size_t)b * ((size_t)N * F + 1) + seg] + slotPos[e];
+            const int dst = ob[(size_t)n * F + f] + slotPos[e];
             entKey[dst] = m;
-            entScale[dst] = weight ? weight[e] : 1.0f / (float)cnt;
+            entScale[dst] = weight ? weight[e] : inv;
         }
     }
 }
@@ -248,9 +253,12 @@ extern "C" int sph3d_graph_transpose_finish(int B, int N, int M, int K, int F,
     hipLaunchKernelGGL(tg_chunk_sums, dim3(B * w.chunks), dim3(256), 0, st, w.L, w.chunks, w.deg, w.sums);
     hipLaunchKernelGGL(tg_scan_sums, dim3(B), dim3(256), 0, st, w.chunks, M * K, w.sums);
     hipLaunchKernelGGL(tg_apply, dim3(B * w.chunks), dim3(256), 0, st, w.L, w.chunks, w.deg, w.sums, offsets);
-    if (total > 0)
-        hipLaunchKernelGGL(tg_fill, dim3((unsigned)blocks), dim3(256), 0, st, B, N, M, K, F, nn_index, nn_count, bin_index,
+    if (total > 0) {
+        long long fb = ((long long)B * M + 3) / 4;          // one wave per graph row
+        if (fb > 65536) fb = 65536;
+        hipLaunchKernelGGL(tg_fill, dim3((unsigned)fb), dim3(256), 0, st, B, N, M, K, F, nn_index, nn_count, bin_index,
                            weight, offsets, w.slot_pos, ent_key, ent_scale);
+    }
     return check_launch("sph3d_graph_transpose");
 }
 
