@@ -381,9 +381,9 @@ def main():
         # among equals the weight-gradient product (split-K + slab sum), then the slowest — NOT simply the slowest, which
         # flips between runs when several level-0 products take within a few percent of each other
         work = 2.0 * ints[0] * ints[1] * ints[2] if "gemm" in name else float(algorithmic_bytes(name, ints))
-        rank = (work, 1 if name.endswith("_tn") else 0, ms / cnt)
-        if rank > f[2]:
-            f[1], f[2] = (name, ints, ms, cnt), rank
+        call_rank = (work, 1 if name.endswith("_tn") else 0, ms / cnt)
+        if call_rank > f[2]:
+            f[1], f[2] = (name, ints, ms, cnt), call_rank
     roofline = None
     families = {k: round(v[0] / ev_steps, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
     if fam:

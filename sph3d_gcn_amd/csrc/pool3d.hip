@@ -152,14 +152,20 @@ __global__ __launch_bounds__(256) void maxpool_bwd(
     int B, int N, int M, int C, const int* __restrict__ maxIndex,
     const float* __restrict__ gradOutput, float* __restrict__ gradInput)
 {
-    const long long total = (long long)B * M * C;
-    const long long stride = (long long)gridDim.x * blockDim.x;
+    // grid.y = cloud: no 64-bit division per element; the channel is carried from iteration to iteration
+    const int b = (int)blockIdx.y;
     const long long per_b = (long long)M * C;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int b = (int)(e / per_b);
-        const int c = (int)(e % C);
-        const int n = maxIndex[e];
-        unsafeAtomicAdd(&gradInput[((size_t)b * N + n) * C + c], gradOutput[e]);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int c = (int)(i0 % C);
+    const int cstep = (int)(stride % C);
+    const int* __restrict__ mi = maxIndex + (size_t)b * per_b;
+    const float* __restrict__ go = gradOutput + (size_t)b * per_b;
+    float* __restrict__ gi = gradInput + (size_t)b * N * C;
+    for (long long e = i0; e < per_b; e += stride) {
+        unsafeAtomicAdd(&gi[(size_t)mi[e] * C + c], go[e]);
+        c += cstep;
+        c = c >= C ? c - C : c;
     }
 }
 
@@ -218,11 +224,13 @@ extern "C" int sph3d_max_pool3d_grad(int B, int N, int M, int C, const int* max_
     hipStream_t st = as_stream(stream);
     int rc = check_hip(hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)B * N * C, st), "sph3d_max_pool3d_grad");
     if (rc) return rc;
-    const long long total = (long long)B * M * C;
-    if (total == 0) return SPH3D_OK;
-    long long blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(maxpool_bwd, dim3((unsigned)blocks), dim3(256), 0, st, B, N, M, C, max_index, grad_output, grad_input);
+    const long long per_b = (long long)M * C;
+    if (per_b == 0) return SPH3D_OK;
+    SPH3D_REQUIRE(B <= 65535, "MaxPool3dGrad: batch %d exceeds the grid's second dimension", B);
+    long long blocks = (per_b + 255) / 256;
+    const long long cap = (8192 + B - 1) / B > 1 ? (8192 + B - 1) / B : 1;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(maxpool_bwd, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, st, B, N, M, C, max_index, grad_output, grad_input);
     return check_launch("sph3d_max_pool3d_grad");
 }
 
