@@ -274,6 +274,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_self_launch(args))
     rank, world, local_rank = hdist.init_from_env()
+    is_rank0 = rank == 0          # (kept apart: the JSON line must not depend on a name that later code could reuse)
     assert world == args.gpus, "launched with WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback in the product path)"
     assert torch.cuda.device_count() >= (local_rank + 1), "rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count())
@@ -442,7 +443,7 @@ def main():
                 conv_gather["tiled_kernel_isolated_frac"] = round(ab / 1e9 / iso_t / HBM_PEAK_GBS, 4)
     sph3d_ms = sum(v[0] for v in per.values()) / ev_steps
 
-    if rank == 0:
+    if is_rank0:
         blocks = world * BLOCKS_PER_GPU * args.steps
         out = {
             "metric": "point-cloud blocks/sec (fwd+bwd) SPH3D_s3dis 8192-pt",

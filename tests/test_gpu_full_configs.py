@@ -216,3 +216,27 @@ def test_fixed_radius_mode_runs_the_model_graph_through_the_plain_kernels():
         assert torch.isfinite(loss).item()
     finally:
         tf_nnquery.set_radius_mode("compat")
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    """the driver depends on `python bench.py` printing ONE JSON line on rank 0: run it (3 steps) as a subprocess and check the
+    contract fields, the roofline object and the conv_gather line"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
+    assert d["unit"] == "blocks/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1
+    assert 0 < d["conv_gather"]["frac"] < 1
