@@ -829,6 +829,10 @@ static int vec_plan(int F, int CR, int r, int& V)
 //   * small levels (N = 128..768: the whole launch is a few hundred sources per XCD): the kernel is a chain of
 //     dependent gathers per source, so the sources are spread over enough workgroups to put two on every CU
 //     (down to 2 sources per wave) instead of leaving most CUs idle.
+#ifndef SPH3D_BWD_FILL
+#define SPH3D_BWD_FILL 128
+#endif
+constexpr int kBwdFillWG = SPH3D_BWD_FILL;   // workgroups per XCD that a small level is spread over (compact kernel: 4 fit a CU)
 static void bwd_plan(int B, int N, int nslices, int wg_per_cu, int& parts, int& W)
 {
     int g = B & 7;                         // gcd(B, 8)
@@ -838,7 +842,7 @@ static void bwd_plan(int B, int N, int nslices, int wg_per_cu, int& parts, int& 
     const long long items_per_xcd = ((long long)B * parts + 7) / 8;
     const long long src = items_per_xcd * ((N + parts - 1) / parts);
     const long long w_work = (src + kBwdTPointsPerWG - 1) / kBwdTPointsPerWG;
-    long long w_fill = 64 / (nslices < 1 ? 1 : nslices);
+    long long w_fill = (wg_per_cu >= 4 ? kBwdFillWG : 64) / (nslices < 1 ? 1 : nslices);
     if (w_fill < 1) w_fill = 1;
     const long long w_min = (src + 2 * kBwdTWaves - 1) / (2 * kBwdTWaves);
     long long w = w_fill < w_min ? w_fill : w_min;
