@@ -23,6 +23,7 @@
 //     (N*C*4 B, 4 MiB at N=8192,C=128) stay in that XCD's 4 MiB L2.
 //   * Numerics: sum_k in*filt in fp32 FMA order k = 0..cnt-1, one division by cnt at the end (the
 //     reference divides every term); agreement with the oracle is ~1e-7 relative, bound 1e-5.
+#include <cstdlib>
 #include "common.hpp"
 
 namespace sph3d {
@@ -744,6 +745,25 @@ extern "C" int sph3d_depthwise_conv3d(int B, int N, int M, int F, int C, int r, 
                        "conv3d: hipFuncSetAttribute");                                                            \
         if (rc) return rc;                                                                                        \
     }
+    if (vec && C > 64 && C <= 128 && (unsigned long long)N * C + 256ull < (1ull << 32)) {
+        // 65..128 channels: 32 lanes per edge, TWO neighbour rows per wave load.  (Round 1 had measured this shape slower than one
+        // row per load, 0.353 vs 0.297 ms at C = 128; with the zero-row padding and vector-side offsets of round 2 it is
+        // 0.202 vs 0.240 ms = 16.6 % of the roofline, ahead of the LDS-tiled kernel and without a plan.  64 lanes per edge for
+        // C >= 256 — one pass over the edges instead of one per 128-channel slice, but 70 KB of filter table per workgroup —
+        // stays behind the row kernel: 0.069 vs 0.060 ms at 2048 x 256.)
+        const int nslices = 1;
+        const size_t lds = (size_t)(F + 1) * C * r * sizeof(float);      // + the zero row of the padding slots
+        const dim3 grid(xcd_grid(B, mblocks * nslices));
+        if (r == 2) {
+            SPH3D_BIG_LDS((dwconv_fwd_multi<2, 32, kFwdSB>))
+            hipLaunchKernelGGL((dwconv_fwd_multi<2, 32, kFwdSB>), grid, dim3(256), lds, st, B, N, M, F, C, K, mblocks,
+                               nslices, nn_index, nn_count, bin_index, input, filter, output);
+        } else {
+            SPH3D_BIG_LDS((dwconv_fwd_multi<1, 32, kFwdSB>))
+            hipLaunchKernelGGL((dwconv_fwd_multi<1, 32, kFwdSB>), grid, dim3(256), lds, st, B, N, M, F, C, K, mblocks,
+                               nslices, nn_index, nn_count, bin_index, input, filter, output);
+        }
+    } else
     if (vec && C <= 64 && (unsigned long long)N * C + 256ull < (1ull << 32)) {
         // narrow layers: 16 lanes per edge, four neighbour rows per wave load (measured at C = 64, r = 2: 0.254 -> 0.145 ms;
         // at C >= 128 the one-edge-per-load kernel below is faster: 0.297 vs 0.353 ms with two edges per load)
