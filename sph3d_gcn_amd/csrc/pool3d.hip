@@ -169,6 +169,82 @@ __global__ __launch_bounds__(256) void maxpool_bwd(
     }
 }
 
+// Few sources with many in-edges each (un-pooling: 2048 coarse points collect ~100 fine points each): one WORKGROUP per
+// source, its four waves take every fourth in-edge and the partial sums meet in LDS.  One wave per source (gather_bwd_t)
+// leaves such a launch with eight waves per SIMD in total and a 100-edge dependent chain per wave: 0.13 ms at the decoder's
+// last level whatever the channel count.  (Two edges per wave load for C <= 128 was measured first: no gain — the launch is
+// latency-, not load-bound.)
+template <int V>
+__global__ __launch_bounds__(256) void gather_bwd_t_split(
+    int B, int Nin, int Mout, int C,
+    const int* __restrict__ offsets, const int* __restrict__ entKey, const float* __restrict__ entScale,
+    const float* __restrict__ gradOutput, float* __restrict__ gradInput)
+{
+    __shared__ float part[4][64 * V];
+    const long long src = (long long)blockIdx.x;
+    const int b = (int)(src / Nin);
+    const int n = (int)(src - (long long)b * Nin);
+    const int wave = uniform((int)threadIdx.x >> 6);
+    const int lane = lane_id();
+    const float* gob = gradOutput + (size_t)b * Mout * C;
+    const int* __restrict__ offb = offsets + (size_t)b * (Nin + 1);
+    const int e0 = offb[n], e1 = offb[n + 1];
+    for (int c0 = 0; c0 < C; c0 += 64 * V) {
+        const int c = c0 + lane * V;
+        const bool act = c < C;
+        const int cc = act ? c : 0;
+        float acc[V];
+#pragma unroll
+        for (int v = 0; v < V; v++) acc[v] = 0.f;
+        if (V == 4 && C <= 128) {
+            // a row is at most 32 lanes wide: the two halves of the wave take alternate edges (one wave load = two rows; the
+            // launch is bound by the L1's 16 cycles per wave load once there are enough waves)
+            const int half = lane >> 5;
+            const int ch = (lane & 31) * 4;
+            const int cch = ch < C ? ch : 0;
+#pragma unroll 4
+            for (int e = e0 + 2 * wave; e < e1; e += 8) {
+                const bool two = (e + 1) < e1;                           // wave-uniform
+                const int m0 = entKey[e], m1 = entKey[two ? e + 1 : e];
+                const float s0 = entScale[e], s1 = two ? entScale[e + 1] : 0.f;
+                const int m = half ? m1 : m0;
+                const float sc = half ? s1 : s0;
+                const float4 t = *reinterpret_cast<const float4*>(&gob[(size_t)m * C + cch]);
+                acc[0] = fmaf(t.x, sc, acc[0]);
+                acc[1 % V] = fmaf(t.y, sc, acc[1 % V]);
+                acc[2 % V] = fmaf(t.z, sc, acc[2 % V]);
+                acc[3 % V] = fmaf(t.w, sc, acc[3 % V]);
+            }
+#pragma unroll
+            for (int v = 0; v < V; v++) acc[v] += __shfl_xor(acc[v], 32);       // lanes 0..31 now hold channels 4*lane..
+        } else
+#pragma unroll 4
+        for (int e = e0 + wave; e < e1; e += 4) {
+            const int m = entKey[e];
+            const float sc = entScale[e];
+            if (V == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(&gob[(size_t)m * C + cc]);
+                acc[0] = fmaf(t.x, sc, acc[0]);
+                acc[1 % V] = fmaf(t.y, sc, acc[1 % V]);
+                acc[2 % V] = fmaf(t.z, sc, acc[2 % V]);
+                acc[3 % V] = fmaf(t.w, sc, acc[3 % V]);
+            } else {
+                acc[0] = fmaf(gob[(size_t)m * C + cc], sc, acc[0]);
+            }
+        }
+        if (c0 > 0) __syncthreads();              // the previous pass's sums have been read
+#pragma unroll
+        for (int v = 0; v < V; v++) part[wave][lane * V + v] = acc[v];
+        __syncthreads();
+        if (wave == 0 && act) {
+#pragma unroll
+            for (int v = 0; v < V; v++)           // fixed order: deterministic
+                gradInput[((size_t)b * Nin + n) * C + c + v] =
+                    ((part[0][lane * V + v] + part[1][lane * V + v]) + part[2][lane * V + v]) + part[3][lane * V + v];
+        }
+    }
+}
+
 template <Mode MODE>
 static int launch_fwd(const char* who, int B, int Nin, int Mout, int C, int K,
                       const int* nn_index, const int* nn_count, const float* input, const float* weight,
@@ -196,6 +272,17 @@ static int launch_bwd_t(const char* who, int B, int Nin, int Mout, int C,
     if (B == 0) return SPH3D_OK;
     const int nblocks = (Nin + kPtsPerWG - 1) / kPtsPerWG;
     const dim3 grid(xcd_grid(B, nblocks));
+    // few sources, each with (Mout / Nin) x more in-edges than a target has neighbours: one workgroup per source
+    if ((long long)B * Nin <= 65536 && Mout >= 2 * Nin) {
+        const dim3 sgrid((unsigned)((long long)B * Nin));
+        if (C % 4 == 0)
+            hipLaunchKernelGGL(gather_bwd_t_split<4>, sgrid, dim3(256), 0, st, B, Nin, Mout, C, offsets, ent_key, ent_scale,
+                               grad_output, grad_input);
+        else
+            hipLaunchKernelGGL(gather_bwd_t_split<1>, sgrid, dim3(256), 0, st, B, Nin, Mout, C, offsets, ent_key, ent_scale,
+                               grad_output, grad_input);
+        return check_launch(who);
+    }
     if (C % 4 == 0)
         hipLaunchKernelGGL(gather_bwd_t<4>, grid, dim3(256), 0, st, B, Nin, Mout, C, nblocks, offsets, ent_key,
                            ent_scale, grad_output, grad_input);
