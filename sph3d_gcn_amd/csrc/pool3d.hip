@@ -94,6 +94,90 @@ __global__ __launch_bounds__(256) void gather_fwd(
     }
 }
 
+// C <= 128 (C % 4 == 0): a row is at most 32 lanes of 16 bytes, so the two halves of the wave take ALTERNATE neighbours (one
+// wave load = two rows): these launches are bound by the L1's 16 cycles per wave load (3.1 M edges at the decoder's last
+// level = 0.08 ms of L1 issue with one row per load, measured 0.128 ms), and with one row per load half the lanes repeat
+// lane 0's address.  Max: each half keeps (value, id, slot) of its own neighbours — half 0 is seeded by neighbour 0 as in
+// the reference (tf_pool3d_gpu.cu:17-29), half 1 starts from -inf — and the halves are merged with "larger value, then
+// earlier slot", which is what the reference's sequential strict-> scan computes.
+template <Mode MODE>
+__global__ __launch_bounds__(256) void gather_fwd_half(
+    int B, int Nin, int Mout, int C, int K, int mblocks,
+    const int* __restrict__ nnIndex, const int* __restrict__ nnCount,
+    const float* __restrict__ input, const float* __restrict__ weight,
+    float* __restrict__ output, int* __restrict__ maxIndex)
+{
+    int b, mb;
+    xcd_decode((int)blockIdx.x, B, mblocks, b, mb);
+    if (b < 0) return;
+    const int wave = uniform((int)threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int half = lane >> 5;
+    const int c = (lane & 31) * 4;
+    const bool act = c < C;
+    const int m_begin = mb * kPtsPerWG;
+    const int m_end = (m_begin + kPtsPerWG) < Mout ? (m_begin + kPtsPerWG) : Mout;
+    const float* inb = input + (size_t)b * Nin * C + (act ? c : 0);
+
+    for (int m = m_begin + wave; m < m_end; m += 4) {
+        const size_t row = (size_t)b * Mout + m;
+        const int cnt = uniform(nnCount[row]);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        int arg[4] = {0, 0, 0, 0}, pos[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+        if (MODE == Mode::Max && half == 1) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) acc[v] = -__builtin_inff();
+        }
+        const int* __restrict__ irow = nnIndex + row * K;
+        const float* __restrict__ wrow = weight + row * K;
+#pragma unroll 4
+        for (int kk = 0; kk < cnt; kk += 2) {
+            const bool two = (kk + 1) < cnt;                         // wave-uniform
+            const int n0 = irow[kk], n1 = irow[two ? kk + 1 : kk];
+            float w0 = 1.f, w1 = two ? 1.f : 0.f;                    // the odd tail: the same row again with weight 0 ...
+            if (MODE == Mode::Weighted) { w0 = wrow[kk]; w1 = two ? wrow[kk + 1] : 0.f; }
+            const int n = half ? n1 : n0;
+            const float w = half ? w1 : w0;
+            const int k = kk + half;
+            const bool real = half == 0 || two;                      // ... or, for max, skipped
+            const float4 t = *reinterpret_cast<const float4*>(&inb[(size_t)n * C]);
+            const float x[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                if (MODE == Mode::Max) {
+                    if (real && (k == 0 || x[v] > acc[v])) { acc[v] = x[v]; arg[v] = n; pos[v] = k; }
+                } else {
+                    acc[v] = fmaf(x[v], w, acc[v]);
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const float ov = __shfl_xor(acc[v], 32);
+            if (MODE == Mode::Max) {
+                const int oa = __shfl_xor(arg[v], 32), op = __shfl_xor(pos[v], 32);
+                // larger value wins, equal values: the earlier slot.  Half 0's seed (slot 0) is kept even when it is NaN,
+                // like the reference's unconditional first assignment: nothing compares greater than NaN
+                if (ov > acc[v] || (ov == acc[v] && op < pos[v])) { acc[v] = ov; arg[v] = oa; pos[v] = op; }
+            } else {
+                acc[v] += ov;
+            }
+        }
+        if (act && half == 0) {
+            float4 o;
+            if (MODE == Mode::Avg) {
+                const float fc = (float)cnt;
+                o = make_float4(cnt > 0 ? acc[0] / fc : 0.f, cnt > 0 ? acc[1] / fc : 0.f, cnt > 0 ? acc[2] / fc : 0.f,
+                                cnt > 0 ? acc[3] / fc : 0.f);
+            } else {
+                o = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            }
+            *reinterpret_cast<float4*>(&output[row * C + c]) = o;
+            if (MODE == Mode::Max) *reinterpret_cast<int4*>(&maxIndex[row * C + c]) = make_int4(arg[0], arg[1], arg[2], arg[3]);
+        }
+    }
+}
+
 // gradient of avg-pool / mean- and weighted-interpolate as a GATHER over the transposed graph (graph.hip):
 //   gradInput[b, n, c] = sum over in-edges (m, scale) of gradOutput[b, m, c] * scale
 // scale = 1/nn_count[m] (avg / mean) or weight[b,m,k] (weighted).  One wave per source point n, each
@@ -255,7 +339,10 @@ static int launch_fwd(const char* who, int B, int Nin, int Mout, int C, int K,
     if (B == 0 || Mout == 0) return SPH3D_OK;
     const int mblocks = (Mout + kPtsPerWG - 1) / kPtsPerWG;
     const dim3 grid(xcd_grid(B, mblocks));
-    if (C % 4 == 0)
+    if (C % 4 == 0 && C <= 128)
+        hipLaunchKernelGGL((gather_fwd_half<MODE>), grid, dim3(256), 0, st, B, Nin, Mout, C, K, mblocks,
+                           nn_index, nn_count, input, weight, output, max_index);
+    else if (C % 4 == 0)
         hipLaunchKernelGGL((gather_fwd<MODE, 4>), grid, dim3(256), 0, st, B, Nin, Mout, C, K, mblocks,
                            nn_index, nn_count, input, weight, output, max_index);
     else
