@@ -505,6 +505,7 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
                         // ds_bpermute (lane number modulo 64, scales masked to the segment: see the full-wave branch)
                         constexpr int NL = SPH3D_BWD_NL;          // wave loads per batch = 2 * NL edges
                         const float svh = ((unsigned)(lane - e0) < (unsigned)(e1 - e0)) ? sv : 0.f;
+                        // (exact-count last batches, which pay in the full-wave branch, measured no gain here: 0.305 vs 0.319 ms)
                         for (int e = e0; e < e1; e += 2 * NL) {
                             const int a4 = ((e + half) << 2);
                             unsigned ko[NL];
@@ -530,31 +531,38 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
                     // v_readlane takes the lane number modulo 64, wrap to lanes below e0) without clamps or selects:
                     // the extra gathers hit valid rows (every lane holds a valid key) and are multiplied by exactly 0
                     const float svm = ((unsigned)(lane - e0) < (unsigned)(e1 - e0)) ? sv : 0.f;
-                    for (int e = e0; e < e1; e += 4) {
-                        // four edges at a time: their row gathers are independent and issued together
-                        float sc[4];
-                        float g[4][V];
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const unsigned ko = (unsigned)__builtin_amdgcn_readlane((int)kel, e + u);
-                            sc[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(svm), e + u));
-                            const float* __restrict__ rp = gou + ko;                // wave-uniform row address
-                            // branch-free (inactive lanes read lane 0's columns): the four gathers stay in one basic block
-                            if (V == 4) {
-                                const float4 t = *reinterpret_cast<const float4*>(&rp[cla]);
-                                g[u][0] = t.x; g[u][1 % V] = t.y; g[u][2 % V] = t.z; g[u][3 % V] = t.w;
-                            } else if (V == 2) {
-                                const float2 t = *reinterpret_cast<const float2*>(&rp[cla]);
-                                g[u][0] = t.x; g[u][1 % V] = t.y;
-                            } else {
-                                g[u][0] = rp[cla];
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; u++)
-#pragma unroll
-                            for (int v = 0; v < V; v++) sg[v] = fmaf(g[u][v], sc[u], sg[v]);
-                    }
+                    // four edges at a time (their row gathers are independent and issued together), then the segment's last one
+                    // to three edges with exactly that many gathers: a padded last batch made a third of all gathers padding
+                    // (8.5 M wave loads for 6.3 M edges at level 0), and these kernels pay 16 L1 cycles per wave load
+#define SPH3D_BWD_BATCH(NB)                                                                                          \
+    {                                                                                                                \
+        float sc[NB];                                                                                                \
+        float g[NB][V];                                                                                              \
+        _Pragma("unroll") for (int u = 0; u < NB; u++) {                                                             \
+            const unsigned ko = (unsigned)__builtin_amdgcn_readlane((int)kel, e + u);                                \
+            sc[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(svm), e + u));                           \
+            const float* __restrict__ rp = gou + ko;                /* wave-uniform row address */                   \
+            /* branch-free (inactive lanes read lane 0's columns): the gathers stay in one basic block */            \
+            if (V == 4) {                                                                                            \
+                const float4 t = *reinterpret_cast<const float4*>(&rp[cla]);                                         \
+                g[u][0] = t.x; g[u][1 % V] = t.y; g[u][2 % V] = t.z; g[u][3 % V] = t.w;                              \
+            } else if (V == 2) {                                                                                     \
+                const float2 t = *reinterpret_cast<const float2*>(&rp[cla]);                                         \
+                g[u][0] = t.x; g[u][1 % V] = t.y;                                                                    \
+            } else {                                                                                                 \
+                g[u][0] = rp[cla];                                                                                   \
+            }                                                                                                        \
+        }                                                                                                            \
+        _Pragma("unroll") for (int u = 0; u < NB; u++)                                                               \
+            _Pragma("unroll") for (int v = 0; v < V; v++) sg[v] = fmaf(g[u][v], sc[u], sg[v]);                       \
+    }
+                    int e = e0;
+                    for (; e + 4 <= e1; e += 4) SPH3D_BWD_BATCH(4)
+                    const int rem = e1 - e;
+                    if (rem == 3) SPH3D_BWD_BATCH(3)
+                    else if (rem == 2) SPH3D_BWD_BATCH(2)
+                    else if (rem == 1) SPH3D_BWD_BATCH(1)
+#undef SPH3D_BWD_BATCH
                     }
 #pragma unroll
                     for (int v = 0; v < V; v++) {
