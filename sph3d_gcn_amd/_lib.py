@@ -51,6 +51,10 @@ SIGNATURES = {
     "sph3d_tile_plan": (_I, [_I] * 5 + [_P] * 11),
     "sph3d_depthwise_conv3d_tiled_supported": (_I, [_I] * 5),
     "sph3d_depthwise_conv3d_tiled": (_I, [_I] * 7 + [_P] * 11),
+    "sph3d_tile2_plan_sizes": (_I, [_I, _I, _P, _P, _P]),
+    "sph3d_tile2_plan": (_I, [_I] * 6 + [_P] * 8),
+    "sph3d_depthwise_conv3d_tiled2_supported": (_I, [_I] * 4),
+    "sph3d_depthwise_conv3d_tiled2": (_I, [_I] * 7 + [_P] * 7),
     "sph3d_scatter_grad_t": (_I, [_I] * 4 + [_P] * 6),
     "sph3d_scatter_grad_workspace": (_S, [_I] * 4),
     "sph3d_mean_interpolate": (_I, [_I] * 5 + [_P] * 5),
