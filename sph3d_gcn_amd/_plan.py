@@ -26,7 +26,7 @@ UCAP = 236            # rows a tile stages: (UCAP + 2) * 512 B of rows + the 33-
 MIN_POINTS = 64       # below this a level is a handful of tiles: the gather kernels are used
 _MAX_ENTRIES = 16
 
-UCAP2 = int(os.environ.get("SPH3D_T2_UCAP", "144"))   # tile2: rows a tile stages (x 512 B at C >= 128: two workgroups per CU)
+UCAP2 = int(os.environ.get("SPH3D_T2_UCAP", "256"))   # tile2: rows a tile stages (x 512 B at C >= 128: two workgroups per CU)
 MIN_POINTS2 = 256
 
 _mode = "gather"      # "gather" | "tiled" | "tiled2": which forward kernel a convolution with a registered graph geometry uses

@@ -34,6 +34,11 @@ constexpr int kFwdPointsPerWG = 32;
 #define SPH3D_FWD_SB 4
 #endif
 constexpr int kFwdSB = SPH3D_FWD_SB;   // dwconv_fwd_multi: wave loads (each EPL neighbour rows) issued together
+#ifndef SPH3D_FWD_WAVES
+#define SPH3D_FWD_WAVES 4
+#endif
+constexpr int kMultiWaves = SPH3D_FWD_WAVES;          // dwconv_fwd_multi: waves per workgroup (they share one LDS filter table)
+constexpr int kMultiPoints = 8 * kMultiWaves;         // output points per workgroup
 constexpr int kBatch = 8;               // dwconv_fwd_row: neighbours whose gathers are issued together
 
 // ------------------------------------------------------------------------------------------
@@ -47,15 +52,16 @@ constexpr int kBatch = 8;               // dwconv_fwd_row: neighbours whose gath
 // The group partial sums are added across lane groups at the end (ds_swizzle-free: two ds_bpermute rounds at most).
 // ------------------------------------------------------------------------------------------
 template <int R, int LPE, int SB>
-__global__ __launch_bounds__(256) void dwconv_fwd_multi(
+__global__ __launch_bounds__(64 * kMultiWaves) void dwconv_fwd_multi(
     int B, int N, int M, int F, int C, int K, int mblocks, int nslices,
     const int* __restrict__ nnIndex, const int* __restrict__ nnCount, const int* __restrict__ binIndex,
     const float* __restrict__ input, const float* __restrict__ filter, float* __restrict__ output)
 {
-    extern __shared__ __attribute__((aligned(16))) float lfilt[];   // [F][SLo]
+    extern __shared__ __attribute__((aligned(16))) float lfilt[];   // [F + 1][R][SLI]: compile-time strides
     constexpr int EPL = 64 / LPE;               // edges per wave load
     constexpr int NO = 4 * R;                   // output channels per lane
     constexpr int SLI = 4 * LPE;                // input channels per slice
+    constexpr int FSTB = SLI * R * 4;           // bytes per filter row in LDS
     const int CR = C * R;
     int b, part;
     xcd_decode((int)blockIdx.x, B, mblocks * nslices, b, part);
@@ -72,11 +78,11 @@ __global__ __launch_bounds__(256) void dwconv_fwd_multi(
         const int f = e / SLo;
         const int cl = e - f * SLo;                 // multiple of 4
         const int l4 = cl / (4 * R), q = (cl >> 2) % R;
-        *reinterpret_cast<float4*>(&lfilt[f * SLo + q * SLi + l4 * 4]) =
+        *reinterpret_cast<float4*>(&lfilt[f * (SLI * R) + q * SLI + l4 * 4]) =
             *reinterpret_cast<const float4*>(&filter[(size_t)f * CR + ci0 * R + cl]);
     }
     // row F: all zeros, the filter row of padding slots (see dwconv_fwd_row)
-    for (int e = threadIdx.x; e < SLo; e += blockDim.x) lfilt[F * SLo + e] = 0.f;
+    for (int e = threadIdx.x; e < SLI * R; e += blockDim.x) lfilt[F * (SLI * R) + e] = 0.f;
     __syncthreads();
 
     const int wave = uniform((int)threadIdx.x >> 6);
@@ -85,11 +91,19 @@ __global__ __launch_bounds__(256) void dwconv_fwd_multi(
     const int li = lane - g * LPE;
     const bool act = li * 4 < SLi;
     const int cic = act ? li * 4 : 0;           // clamped copy for branch-free loads
-    const int m_begin = mb * kFwdPointsPerWG;
-    const int m_end = (m_begin + kFwdPointsPerWG) < M ? (m_begin + kFwdPointsPerWG) : M;
-    const float* inb = input + (size_t)b * N * C + ci0 + cic;
+    const int m_begin = mb * kMultiPoints;
+    const int m_end = (m_begin + kMultiPoints) < M ? (m_begin + kMultiPoints) : M;
+    // Instruction diet (round 3; the kernel is bound by instruction ISSUE, ~4.4 SIMD cycles per wave instruction, not by
+    // bytes: profiles/r03_pmc_sq_*): uniform row base + 32-bit per-lane byte offsets (no 64-bit vector adds), ONE cross-lane
+    // hand-over per edge (neighbour id and bin id packed in a word: id in the low 24 bits, so v_mul_u32_u24 turns the word
+    // into the row's byte offset without masking it), the second filter quad at an immediate LDS offset, one reciprocal per
+    // point instead of a correctly rounded division per output.
+    const char* inb = reinterpret_cast<const char*>(input + (size_t)b * N * C + ci0);
+    const unsigned cicb = (unsigned)cic * 4u;
+    const unsigned rowb = (unsigned)C * 4u;     // bytes per input row (< 2^24: launcher)
+    const char* lfb = reinterpret_cast<const char*>(lfilt);
 
-    for (int m = m_begin + wave; m < m_end; m += 4) {
+    for (int m = m_begin + wave; m < m_end; m += kMultiWaves) {
         const size_t row = (size_t)b * M + m;
         const int cnt = uniform(nnCount[row]);
         float acc[NO];
@@ -104,30 +118,29 @@ __global__ __launch_bounds__(256) void dwconv_fwd_multi(
             int binv = binIndex[row * K + mykc];
             binv = binv < 0 ? 0 : (binv >= F ? F - 1 : binv);     // out-of-range bin ids: same clamp as the transposed graph
             binv = myk < cnt ? binv : F;
-            const unsigned noff = (unsigned)idxv * (unsigned)C;    // element offsets, once per 64 edges (N * C < 2^32: launcher)
-            const int foff = binv * (SLo >> 2);                    // float4 units: the LDS reads stay 16-byte aligned
+            const unsigned pk = (unsigned)idxv | ((unsigned)binv << 24);      // N <= 2^24, F <= 254: launcher
             static_assert(64 % (SB * EPL) == 0, "batches must tile the 64-edge chunk (no index clamps)");
             // ... then consumed SB wave loads (SB*EPL edges) at a time: all their gathers are in flight before the
             // first FMA (the kernel is latency-bound otherwise)
             for (int k0 = 0; k0 < kn; k0 += SB * EPL) {
                 float4 x[SB];
-                int fo[SB];
+                unsigned fo[SB];
 #pragma unroll
                 for (int u = 0; u < SB; u++) {
                     // lane group g takes edge k0 + u*EPL + g.  Measured: ds_bpermute (0.145 ms at C = 64) beats EPL v_readlane
-                    // broadcasts + per-lane selects (0.203 ms) — the selects and the per-lane address arithmetic cost more
-                    // VALU time than the LDS round trip
+                    // broadcasts + per-lane selects (0.203 ms)
                     const int kq = k0 + u * EPL + g;               // <= 63: padding slots hold a real row and the zero filter row
-                    const unsigned n = (unsigned)__shfl((int)noff, kq);
-                    fo[u] = __shfl(foff, kq);
-                    x[u] = *reinterpret_cast<const float4*>(&inb[n]);
+                    const unsigned p = (unsigned)__shfl((int)pk, kq);
+                    const unsigned off = __umul24(p, rowb) + cicb;                 // low 24 bits of p = neighbour id
+                    fo[u] = __umul24(p >> 24, (unsigned)FSTB) + cicb;
+                    x[u] = *reinterpret_cast<const float4*>(inb + off);
                 }
 #pragma unroll
                 for (int u = 0; u < SB; u++) {
                     const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
 #pragma unroll
                     for (int q = 0; q < R; q++) {
-                        const float4 w = reinterpret_cast<const float4*>(lfilt)[fo[u] + ((q * SLi + cic) >> 2)];
+                        const float4 w = *reinterpret_cast<const float4*>(lfb + fo[u] + q * (SLI * 4));
                         // outputs 4q..4q+3 of this lane belong to input channels (4q + j) / R
                         acc[4 * q + 0] = fmaf(xs[(4 * q + 0) / R], w.x, acc[4 * q + 0]);
                         acc[4 * q + 1] = fmaf(xs[(4 * q + 1) / R], w.y, acc[4 * q + 1]);
@@ -143,15 +156,17 @@ __global__ __launch_bounds__(256) void dwconv_fwd_multi(
 #pragma unroll
             for (int v = 0; v < NO; v++) acc[v] += __shfl_xor(acc[v], o);
         if (act && g == 0) {
-            const float fc = (float)cnt;   // cnt == 0 only for rows the caller marked empty: output 0
+            // cnt == 0 only for rows the caller marked empty: output 0.  One reciprocal per point (1 ulp from the per-term
+            // divisions of the reference; the bound on the op is 1e-5)
+            const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.f;
             float* op = &output[row * CR + (size_t)(ci0 + li * 4) * R];
 #pragma unroll
             for (int q = 0; q < R; q++) {
                 float4 o;
-                o.x = cnt > 0 ? acc[4 * q + 0] / fc : 0.f;
-                o.y = cnt > 0 ? acc[4 * q + 1] / fc : 0.f;
-                o.z = cnt > 0 ? acc[4 * q + 2] / fc : 0.f;
-                o.w = cnt > 0 ? acc[4 * q + 3] / fc : 0.f;
+                o.x = acc[4 * q + 0] * inv;
+                o.y = acc[4 * q + 1] * inv;
+                o.z = acc[4 * q + 2] * inv;
+                o.w = acc[4 * q + 3] * inv;
                 *reinterpret_cast<float4*>(&op[4 * q]) = o;
             }
         }
@@ -256,12 +271,14 @@ __global__ __launch_bounds__(256) void dwconv_fwd_row(
             }
         }
         if (act) {
-            const float fc = (float)cnt;   // cnt == 0 only for rows the caller marked empty: output 0
+            // cnt == 0 only for rows the caller marked empty: output 0.  One reciprocal per point, not a correctly rounded
+            // division per output (4 x ~11 instructions per lane and point on an issue-bound kernel)
+            const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.f;
             float4 o;
-            o.x = cnt > 0 ? acc.x / fc : 0.f;
-            o.y = cnt > 0 ? acc.y / fc : 0.f;
-            o.z = cnt > 0 ? acc.z / fc : 0.f;
-            o.w = cnt > 0 ? acc.w / fc : 0.f;
+            o.x = acc.x * inv;
+            o.y = acc.y * inv;
+            o.z = acc.z * inv;
+            o.w = acc.w * inv;
             *reinterpret_cast<float4*>(&output[row * CR + slice0 + cl0]) = o;
         }
     }
@@ -753,38 +770,41 @@ extern "C" int sph3d_depthwise_conv3d(int B, int N, int M, int F, int C, int r, 
                        "conv3d: hipFuncSetAttribute");                                                            \
         if (rc) return rc;                                                                                        \
     }
-    if (vec && C > 64 && C <= 128 && (unsigned long long)N * C + 256ull < (1ull << 32)) {
+    const int mmblocks = (M + kMultiPoints - 1) / kMultiPoints;
+    const dim3 mgrid(xcd_grid(B, mmblocks));
+    const bool multi_ok = vec && N <= (1 << 24) && F <= 254 && (unsigned long long)N * C * 4ull + 1024ull < (1ull << 32);
+    if (multi_ok && C > 64 && C <= 128) {
         // 65..128 channels: 32 lanes per edge, TWO neighbour rows per wave load.  (Round 1 had measured this shape slower than one
         // row per load, 0.353 vs 0.297 ms at C = 128; with the zero-row padding and vector-side offsets of round 2 it is
         // 0.202 vs 0.240 ms = 16.6 % of the roofline, ahead of the LDS-tiled kernel and without a plan.  64 lanes per edge for
         // C >= 256 — one pass over the edges instead of one per 128-channel slice, but 70 KB of filter table per workgroup —
         // stays behind the row kernel: 0.069 vs 0.060 ms at 2048 x 256.)
         const int nslices = 1;
-        const size_t lds = (size_t)(F + 1) * C * r * sizeof(float);      // + the zero row of the padding slots
+        const size_t lds = (size_t)(F + 1) * 128 * r * sizeof(float);    // + the zero row of the padding slots; rows of 128 * r
         const dim3 grid(xcd_grid(B, mblocks * nslices));
         if (r == 2) {
             SPH3D_BIG_LDS((dwconv_fwd_multi<2, 32, kFwdSB>))
-            hipLaunchKernelGGL((dwconv_fwd_multi<2, 32, kFwdSB>), grid, dim3(256), lds, st, B, N, M, F, C, K, mblocks,
+            hipLaunchKernelGGL((dwconv_fwd_multi<2, 32, kFwdSB>), mgrid, dim3(64 * kMultiWaves), lds, st, B, N, M, F, C, K, mmblocks,
                                nslices, nn_index, nn_count, bin_index, input, filter, output);
         } else {
             SPH3D_BIG_LDS((dwconv_fwd_multi<1, 32, kFwdSB>))
-            hipLaunchKernelGGL((dwconv_fwd_multi<1, 32, kFwdSB>), grid, dim3(256), lds, st, B, N, M, F, C, K, mblocks,
+            hipLaunchKernelGGL((dwconv_fwd_multi<1, 32, kFwdSB>), mgrid, dim3(64 * kMultiWaves), lds, st, B, N, M, F, C, K, mmblocks,
                                nslices, nn_index, nn_count, bin_index, input, filter, output);
         }
     } else
-    if (vec && C <= 64 && (unsigned long long)N * C + 256ull < (1ull << 32)) {
+    if (multi_ok && C <= 64) {
         // narrow layers: 16 lanes per edge, four neighbour rows per wave load (measured at C = 64, r = 2: 0.254 -> 0.145 ms;
         // at C >= 128 the one-edge-per-load kernel below is faster: 0.297 vs 0.353 ms with two edges per load)
         const int nslices = 1;
-        const size_t lds = (size_t)(F + 1) * C * r * sizeof(float);      // + the zero row of the padding slots
+        const size_t lds = (size_t)(F + 1) * 64 * r * sizeof(float);     // + the zero row of the padding slots; rows of 64 * r
         const dim3 grid(xcd_grid(B, mblocks * nslices));
         if (r == 2) {
             SPH3D_BIG_LDS((dwconv_fwd_multi<2, 16, kFwdSB>))
-            hipLaunchKernelGGL((dwconv_fwd_multi<2, 16, kFwdSB>), grid, dim3(256), lds, st, B, N, M, F, C, K, mblocks,
+            hipLaunchKernelGGL((dwconv_fwd_multi<2, 16, kFwdSB>), mgrid, dim3(64 * kMultiWaves), lds, st, B, N, M, F, C, K, mmblocks,
                                nslices, nn_index, nn_count, bin_index, input, filter, output);
         } else {
             SPH3D_BIG_LDS((dwconv_fwd_multi<1, 16, kFwdSB>))
-            hipLaunchKernelGGL((dwconv_fwd_multi<1, 16, kFwdSB>), grid, dim3(256), lds, st, B, N, M, F, C, K, mblocks,
+            hipLaunchKernelGGL((dwconv_fwd_multi<1, 16, kFwdSB>), mgrid, dim3(64 * kMultiWaves), lds, st, B, N, M, F, C, K, mmblocks,
                                nslices, nn_index, nn_count, bin_index, input, filter, output);
         }
     } else if (vec && (unsigned long long)N * C + 256ull < (1ull << 32)) {       // (32-bit row offsets in the kernel)

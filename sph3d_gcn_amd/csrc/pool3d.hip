@@ -82,10 +82,11 @@ __global__ __launch_bounds__(256) void gather_fwd(
                 }
             }
             if (act) {
+                const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.f;
 #pragma unroll
                 for (int v = 0; v < V; v++) {
                     float o = acc[v];
-                    if (MODE == Mode::Avg) o = cnt > 0 ? o / (float)cnt : 0.f;
+                    if (MODE == Mode::Avg) o = o * inv;
                     output[row * C + c + v] = o;
                     if (MODE == Mode::Max) maxIndex[row * C + c + v] = arg[v];
                 }
@@ -166,9 +167,8 @@ __global__ __launch_bounds__(256) void gather_fwd_half(
         if (act && half == 0) {
             float4 o;
             if (MODE == Mode::Avg) {
-                const float fc = (float)cnt;
-                o = make_float4(cnt > 0 ? acc[0] / fc : 0.f, cnt > 0 ? acc[1] / fc : 0.f, cnt > 0 ? acc[2] / fc : 0.f,
-                                cnt > 0 ? acc[3] / fc : 0.f);
+                const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.f;      // one reciprocal per point (see conv3d.hip)
+                o = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
             } else {
                 o = make_float4(acc[0], acc[1], acc[2], acc[3]);
             }

@@ -33,9 +33,9 @@
 
 namespace sph3d {
 
-constexpr int kT2Chunk = 32;          // targets per chunk (= per consumer workgroup)
-constexpr int kT2MaxT = 16;           // targets per tile (two per wave of the 8-wave consumer)
-constexpr int kT2HdrInts = 72;        // 1 + 2*32, padded
+constexpr int kT2Chunk = 64;          // targets per chunk: tiles never span chunks
+constexpr int kT2MaxT = 32;           // targets per tile (two per wave of the 16-wave consumer)
+constexpr int kT2HdrInts = 136;       // 1 + 2*64, padded
 constexpr int kT2RecWords = 64;
 constexpr int kT2UlistPerChunk = kT2Chunk * 64;
 
@@ -213,7 +213,16 @@ __global__ __launch_bounds__(256) void tile2_plan_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// forward
+// forward.  ONE persistent 16-wave workgroup per CU walks a contiguous range of chunks (XCD-affine: the clouds of an XCD
+// stay in its L2).  Per tile: LDS-DMA of the tile's rows (ids fetched one tile ahead), barrier, every wave gathers up to two
+// whole targets from LDS, barrier.  Measured dead ends of this round (kept in git history):
+//   * 8-wave workgroups, two per CU, tiles of <= 16 targets, one chunk per workgroup, two edges per trip: 258 us at the
+//     north-star shape (skeleton 36 + staging 39 + gather 190: a wave's dependent readlane -> add -> ds_read -> add chain per
+//     group, four waves per SIMD, nothing overlapping);
+//   * double-buffered rows + LDS filter + 2-4 waves sharing a target (partials through LDS): 372 us.  Small tiles (ucap 112
+//     -> 4 targets) make the per-tile bookkeeping (~600 instructions per wave) the whole cost.
+// What this version does instead: BIG tiles (up to 32 targets, ~250 rows) so that the per-tile work is amortised over
+// ~1500 edges, eight LDS reads in flight per wave whatever the group structure, no divisions in the loop.
 // ---------------------------------------------------------------------------------------------------------------
 template <int NV>
 struct Vec;
@@ -224,204 +233,46 @@ struct Vec<2> { using type = float __attribute__((ext_vector_type(2))); };
 template <>
 struct Vec<4> { using type = float __attribute__((ext_vector_type(4))); };
 
-// R = depth multiplier (1, 2); VEC = channels per lane: 1 (64-channel slice, 256-B rows) or 2 (128-channel slice, 512-B rows);
-// UNR = edges per inner trip
-template <int R, int VEC, int UNR>
-__global__ __launch_bounds__(512) void dwconv_tile2_fwd(
-    int B, int N, int M, int F, int C, int nchunks, int nslices,
-    const int* __restrict__ chdr, const unsigned* __restrict__ rec, const unsigned short* __restrict__ ulist,
-    const float* __restrict__ input, const float* __restrict__ filter, float* __restrict__ output, int dbg)
+constexpr int kT2Waves = 16;
+
+template <int R, int VEC, typename WV>
+__device__ __forceinline__ void t2_flush(float (&acc)[VEC * R], typename Vec<VEC>::type s, WV wf)
 {
-    extern __shared__ __attribute__((aligned(16))) float rows[];      // [ucap][64 * VEC]
-    constexpr int SLC = 64 * VEC;                 // channels per slice
-    constexpr int ROWB = SLC * 4;                 // bytes per staged row
-    constexpr int RPI = 1024 / ROWB;              // rows per 1-KB DMA instruction (2 or 4)
-    constexpr int LPR = 64 / RPI;                 // lanes per row in a DMA instruction
-    constexpr int NO = VEC * R;                   // outputs per lane
-    using xv_t = typename Vec<VEC>::type;
-    using wv_t = typename Vec<NO>::type;
-    int b, part;
-    xcd_decode((int)blockIdx.x, B, nchunks * nslices, b, part);
-    if (b < 0) return;
-    const int slice = part % nslices;             // the slices of a chunk are neighbours in the grid: they share the plan lines in L2
-    const int ch = part / nslices;
-    const int c0 = slice * SLC;
-    const int wave = uniform((int)threadIdx.x >> 6);
-    const int lane = lane_id();
-    const size_t chunk = (size_t)b * nchunks + ch;
-    const int CR = C * R;
-
-    // chunk header: lane t holds tile t's two words
-    const int* hp = chdr + chunk * kT2HdrInts;
-    const int nt = uniform(hp[0]);
-    const int lt = lane < kT2Chunk ? lane : 0;
-    const int hA = hp[1 + 2 * lt];
-    const int hO = hp[2 + 2 * lt];
-    const unsigned short* ulc = ulist + chunk * kT2UlistPerChunk;
-    const float* inb = input + (size_t)b * N * C + c0 + (lane % LPR) * 4;
-    const char* rbase = reinterpret_cast<const char*>(rows) + lane * (VEC * 4);
-    const float* fbase = filter + (size_t)(c0 + lane * VEC) * R;
-    float* outb = output + (size_t)b * M * CR + (size_t)(c0 + lane * VEC) * R;
-
-    // row ids this wave stages for a tile: rows [wave*RW, +RW), RW = rows per wave (multiple of RPI)
-    auto ids_of = [&](int a, int uoff) -> int {
-        const int U = a >> 16;
-        const int RW = ((U + 8 * RPI - 1) / (8 * RPI)) * RPI;
-        const int r = wave * RW + lane;
-        int v = 0;
-        if (lane < RW && r < U) v = ulc[uoff + r];
-        return v;
-    };
-    int a = __builtin_amdgcn_readlane(hA, 0), uoff = __builtin_amdgcn_readlane(hO, 0);
-    int ids = nt > 0 ? ids_of(a, uoff) : 0;
-    for (int t = 0; t < nt; t++) {
-        const int tstart = a & 0xff, T = (a >> 8) & 0xff, U = a >> 16;
-        const int RW = ((U + 8 * RPI - 1) / (8 * RPI)) * RPI;
-        // ---- stage the tile's rows: LDS-DMA, RPI rows per wave instruction ----
-        for (int j = 0; j < RW; j += RPI) {
-            const int i0 = wave * RW + j;
-            if (i0 >= U || (dbg & 1)) break;
-            int rid = __builtin_amdgcn_readlane(ids, j);
-#pragma unroll
-            for (int q = 1; q < RPI; q++) {
-                const int rq = __builtin_amdgcn_readlane(ids, j + q);     // rows past U: id 0 (a valid row, never read)
-                rid = (lane / LPR) == q ? rq : rid;
-            }
-            const float* gp = inb + (size_t)rid * C;
-            float* lp = rows + (size_t)i0 * SLC;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                             (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
+    constexpr int NO = VEC * R;
+    if constexpr (VEC == 1) {
+        if constexpr (R == 1) acc[0] = fmaf(s, wf, acc[0]);
+        else {
+            acc[0] = fmaf(s, wf[0], acc[0]);
+            acc[1] = fmaf(s, wf[1], acc[1]);
         }
-        // the targets' records (independent of the rows) and the next tile's row ids: in flight under the DMA
-        unsigned rv[2];
+    } else {
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int jj = wave + 8 * h;
-            const int q = jj < T ? tstart + jj : tstart;
-            rv[h] = rec[(chunk * kT2Chunk + q) * kT2RecWords + lane];
-        }
-        int a_n = 0, uoff_n = 0, ids_n = 0;
-        if (t + 1 < nt) {
-            a_n = __builtin_amdgcn_readlane(hA, t + 1);
-            uoff_n = __builtin_amdgcn_readlane(hO, t + 1);
-            ids_n = ids_of(a_n, uoff_n);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // ---- gather from LDS: one wave per target ----
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int jj = wave + 8 * h;
-            if (jj >= T || (dbg & 2)) break;
-            const unsigned r0 = rv[h];
-            const int cnt = __builtin_amdgcn_readlane((int)r0, 48);
-            const int ng = __builtin_amdgcn_readlane((int)r0, 49);
-            const int m = __builtin_amdgcn_readlane((int)r0, 50);
-            // lane e <- slot byte of edge e (words 0..15), lane g <- group g (u16 in words 16..47)
-            const unsigned ew = (unsigned)__builtin_amdgcn_ds_bpermute((lane >> 2) << 2, (int)r0);
-            const int eoff = (int)((ew >> ((lane & 3) * 8)) & 0xffu) * ROWB;
-            const unsigned gw = (unsigned)__builtin_amdgcn_ds_bpermute((16 + (lane >> 1)) << 2, (int)r0);
-            const int grp = (int)((gw >> ((lane & 1) * 16)) & 0xffffu);
-            float acc[NO];
-#pragma unroll
-            for (int v = 0; v < NO; v++) acc[v] = 0.f;
-            int e = 0;
-            int gd = __builtin_amdgcn_readlane(grp, 0);
-            wv_t wn = *reinterpret_cast<const wv_t*>(fbase + (size_t)(gd >> 8) * CR);
-            for (int g = 0; g < ng; g++) {
-                const int end = gd & 0xff;
-                const wv_t wf = wn;
-                if (g + 1 < ng) {
-                    gd = __builtin_amdgcn_readlane(grp, g + 1);
-                    if (!(dbg & 4)) wn = *reinterpret_cast<const wv_t*>(fbase + (size_t)(gd >> 8) * CR);
-                }
-                xv_t s = {};
-                if (dbg & 8) e = end;
-                for (; e + UNR <= end; e += UNR) {
-                    xv_t x[UNR];
-#pragma unroll
-                    for (int u = 0; u < UNR; u++) {
-                        const int o = __builtin_amdgcn_readlane(eoff, e + u);
-                        x[u] = *reinterpret_cast<const xv_t*>(rbase + o);
-                    }
-#pragma unroll
-                    for (int u = 0; u < UNR; u++) s += x[u];
-                }
-                for (; e < end; e++) {
-                    const int o = __builtin_amdgcn_readlane(eoff, e);
-                    s += *reinterpret_cast<const xv_t*>(rbase + o);
-                }
-                if constexpr (VEC == 1) {
-                    if constexpr (R == 1) acc[0] = fmaf(s, wf, acc[0]);
-                    else {
-                        acc[0] = fmaf(s, wf[0], acc[0]);
-                        acc[1] = fmaf(s, wf[1], acc[1]);
-                    }
-                } else {
-#pragma unroll
-                    for (int v = 0; v < NO; v++) acc[v] = fmaf(s[v / R], wf[v], acc[v]);
-                }
-            }
-            const float fc = (float)cnt;
-            wv_t o;
-            if constexpr (NO == 1) o = cnt > 0 ? acc[0] / fc : 0.f;
-            else {
-#pragma unroll
-                for (int v = 0; v < NO; v++) o[v] = cnt > 0 ? acc[v] / fc : 0.f;
-            }
-            *reinterpret_cast<wv_t*>(outb + (size_t)m * CR) = o;
-        }
-        __syncthreads();
-        a = a_n;
-        uoff = uoff_n;
-        ids = ids_n;
+        for (int v = 0; v < NO; v++) acc[v] = fmaf(s[v / R], wf[v], acc[v]);
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// forward, persistent + double-buffered (the default): ONE 16-wave workgroup per CU walks a contiguous range of chunks.
-//   * two row buffers: while tile k is gathered from one, the LDS-DMA loads of tile k+1 land in the other (the loads need no
-//     registers, so the "pipeline" is an issue order, not a register scheme); row ids are fetched two tiles ahead, target
-//     records one tile ahead;
-//   * the filter slice lives in LDS (staged once per workgroup).  It must NOT come from global memory here: vmcnt is an
-//     in-order counter, so waiting for a filter row requested after the DMA loads would wait for the DMA loads too and
-//     serialise staging with gathering again;
-//   * a tile has T <= 16 targets, on average 4-7 (ucap rows): nsub = 4 / 3 / 2 / 1 waves share a target's edge list (equal
-//     ranges of the bin-sorted list; a group cut by a range boundary is simply summed in two parts, the op is linear) and the
-//     sub-waves' partial outputs meet in a 12-KB LDS slab;
-//   * edges are consumed 8 at a time whatever the group structure: 8 v_readlane + 8 ds_read_b64 in flight, then the adds, with
-//     the (wave-uniform) group-end test after each.
-// LDS: 2 * ucap * SLC * 4 (rows) + F * SLC * R * 4 (filter) + 12 * 64 * NO * 4 (partials).
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int kT2Waves = 16;
-constexpr int kT2CombSlots = 12;
-
-__device__ __forceinline__ int t2_nsub(int T) { return T <= 4 ? 4 : (T <= 5 ? 3 : (T <= 8 ? 2 : 1)); }
-
+// R = depth multiplier (1, 2); VEC = channels per lane: 1 (64-channel slice, 256-B rows) or 2 (128-channel slice, 512-B rows)
 template <int R, int VEC>
-__global__ __launch_bounds__(1024) void dwconv_tile2p_fwd(
+__global__ __launch_bounds__(1024) void dwconv_tile2_fwd(
     int B, int N, int M, int F, int C, int nchunks, int nslices, int ucap,
     const int* __restrict__ chdr, const unsigned* __restrict__ rec, const unsigned short* __restrict__ ulist,
     const float* __restrict__ input, const float* __restrict__ filter, float* __restrict__ output, int dbg)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) float rows[];      // [ucap][SLC] rows, then [F][SLC * R] filter slice
     constexpr int SLC = 64 * VEC;
     constexpr int ROWB = SLC * 4;
-    constexpr int RPI = 1024 / ROWB;
+    constexpr int RPI = 1024 / ROWB;              // rows per 1-KB DMA instruction (2 or 4)
     constexpr int LPR = 64 / RPI;
     constexpr int NO = VEC * R;
     using xv_t = typename Vec<VEC>::type;
     using wv_t = typename Vec<NO>::type;
-    float* rows = lds;                                        // [2][ucap][SLC]
-    float* lfilt = lds + (size_t)2 * ucap * SLC;              // [F][SLC * R]
-    float* comb = lfilt + (size_t)F * SLC * R;                // [kT2CombSlots][64 * NO]
     const int tid = (int)threadIdx.x;
     const int wave = uniform(tid >> 6);
     const int lane = lane_id();
     const int CR = C * R;
 
-    // ---- this workgroup's slice and range of chunks (flat index f = cloud-local order of the XCD's clouds) ----
-    const int WPX = (int)gridDim.x >> 3;                      // workgroups per XCD
+    // ---- this workgroup's slice and range of chunks (flat index over the chunks of the XCD's clouds) ----
+    const int WPX = (int)gridDim.x >> 3;
     const int xcd = (int)blockIdx.x & 7;
     const int wi = (int)blockIdx.x >> 3;
     const int slice = wi % nslices;
@@ -440,14 +291,11 @@ __global__ __launch_bounds__(1024) void dwconv_tile2p_fwd(
     }
     const int f_begin = (int)(total * gpart / gparts);
     const int f_end = (int)(total * (gpart + 1) / gparts);
-    auto chunk_of = [&](int f) -> size_t {                    // flat index -> global chunk index (cloud * nchunks + ch)
-        const int cl = f / nchunks, ch = f - cl * nchunks;
-        const int b = affine ? xcd + 8 * cl : cl;
-        return (size_t)b * nchunks + ch;
-    };
+    if (f_begin >= f_end) return;
     const int c0 = slice * SLC;
-
-    // ---- filter slice -> LDS ----
+    // ---- filter slice -> LDS, once per workgroup.  (From global memory the row of the next group arrives ~800 cycles after
+    // it is asked for, a group is ~6 edges = ~150 cycles of work: measured 195 us of gather time, most of it these waits.)
+    float* lfilt = rows + (size_t)ucap * SLC;
     {
         const int SLo = SLC * R;
         for (int e = tid * 4; e < F * SLo; e += kT2Waves * 64 * 4) {
@@ -455,183 +303,166 @@ __global__ __launch_bounds__(1024) void dwconv_tile2p_fwd(
             *reinterpret_cast<float4*>(&lfilt[e]) = *reinterpret_cast<const float4*>(&filter[(size_t)f * CR + (size_t)c0 * R + j]);
         }
     }
-    if (f_begin >= f_end) return;
 
-    // ---- tile cursor: three tiles deep (k, k+1, k+2); headers of the chunk of tile k+2 and of the chunk after it ----
-    auto load_hdr = [&](int f, int& hA, int& hO) {
-        const int* hp = chdr + chunk_of(f) * kT2HdrInts;
-        const int lt = lane < kT2Chunk ? lane : 0;
-        hA = lane == 32 ? hp[0] : hp[1 + 2 * lt];
-        hO = hp[2 + 2 * lt];
+    // ---- tile cursor: header of the current chunk in lanes (tile t -> lane t), the next chunk's prefetched ----
+    int fH = f_begin;
+    int clH = f_begin / nchunks, chH = f_begin - clH * nchunks;          // cloud slot, chunk inside the cloud
+    auto chunk_index = [&](int cl, int ch) -> int { return (affine ? xcd + 8 * cl : cl) * nchunks + ch; };
+    auto load_hdr = [&](int cl, int ch, int& hA, int& hO, int& hN) {
+        const int* hp = chdr + (size_t)chunk_index(cl, ch) * kT2HdrInts;
+        hN = hp[0];
+        hA = hp[1 + 2 * lane];
+        hO = hp[2 + 2 * lane];
     };
-    int hA, hO, hA2 = 0, hO2 = 0;
-    load_hdr(f_begin, hA, hO);
-    if (f_begin + 1 < f_end) load_hdr(f_begin + 1, hA2, hO2);
-    int fH = f_begin;                                         // chunk whose header is in (hA, hO)
-    int tH = -1;                                              // tile of that chunk the cursor last produced
-    int ntH = __builtin_amdgcn_readlane(hA, 32);
-    // tile descriptor: valid, global chunk index, a word, ulist offset
-    struct Tile { int valid; size_t chunk; int a, uoff; };
+    int hA, hO, hN, hA2 = 0, hO2 = 0, hN2 = 0;
+    load_hdr(clH, chH, hA, hO, hN);
+    {
+        int ch2 = chH + 1, cl2 = clH;
+        if (ch2 == nchunks) { ch2 = 0; cl2++; }
+        if (fH + 1 < f_end) load_hdr(cl2, ch2, hA2, hO2, hN2);
+    }
+    int ntH = uniform(hN);
+    int tH = -1;
+    struct Tile { int valid, b, chunk, a, uoff; };
     auto next_tile = [&]() -> Tile {
         Tile t;
-        t.valid = 0; t.chunk = 0; t.a = 0; t.uoff = 0;
+        t.valid = 0; t.b = 0; t.chunk = 0; t.a = 0; t.uoff = 0;
         for (;;) {
             if (tH + 1 < ntH) {
                 tH++;
                 t.valid = 1;
-                t.chunk = chunk_of(fH);
+                t.b = affine ? xcd + 8 * clH : clH;
+                t.chunk = t.b * nchunks + chH;
                 t.a = __builtin_amdgcn_readlane(hA, tH);
                 t.uoff = __builtin_amdgcn_readlane(hO, tH);
                 return t;
             }
             if (fH + 1 >= f_end) return t;
             fH++;
+            chH++;
+            if (chH == nchunks) { chH = 0; clH++; }
             hA = hA2;
             hO = hO2;
+            ntH = uniform(hN2);
             tH = -1;
-            ntH = __builtin_amdgcn_readlane(hA, 32);
-            if (fH + 1 < f_end) load_hdr(fH + 1, hA2, hO2);
+            int ch2 = chH + 1, cl2 = clH;
+            if (ch2 == nchunks) { ch2 = 0; cl2++; }
+            if (fH + 1 < f_end) load_hdr(cl2, ch2, hA2, hO2, hN2);
         }
     };
+    // a word of a tile: first target | targets << 8 | rows << 16
+    auto rows_per_wave = [&](int U) -> int { return ((U + kT2Waves * RPI - 1) / (kT2Waves * RPI)) * RPI; };
     auto ids_of = [&](const Tile& t) -> int {
         const int U = t.a >> 16;
-        const int RW = ((U + kT2Waves * RPI - 1) / (kT2Waves * RPI)) * RPI;
+        const int RW = rows_per_wave(U);
         const int r = wave * RW + lane;
         int v = 0;
-        if (t.valid && lane < RW && r < U) v = ulist[t.chunk * kT2UlistPerChunk + t.uoff + r];
+        if (t.valid && lane < RW && r < U) v = ulist[(size_t)t.chunk * kT2UlistPerChunk + t.uoff + r];
         return v;
     };
-    auto rec_of = [&](const Tile& t) -> unsigned {
+    auto rec_of = [&](const Tile& t, int h) -> unsigned {
         const int tstart = t.a & 0xff, T = (t.a >> 8) & 0xff;
-        const int ns = t2_nsub(T);
-        int j = ns == 4 ? wave >> 2 : (ns == 2 ? wave >> 1 : (ns == 1 ? wave : wave / 3));
-        j = j < T ? j : 0;
+        const int jj = wave + kT2Waves * h;
         unsigned v = 0u;
-        if (t.valid) v = rec[(t.chunk * kT2Chunk + tstart + j) * kT2RecWords + lane];
+        if (t.valid && jj < T) v = rec[((size_t)t.chunk * kT2Chunk + tstart + jj) * kT2RecWords + lane];
         return v;
-    };
-    auto issue_dma = [&](const Tile& t, int ids, int buf) {
-        if (!t.valid || (dbg & 1)) return;
-        const int U = t.a >> 16;
-        const int RW = ((U + kT2Waves * RPI - 1) / (kT2Waves * RPI)) * RPI;
-        const int b = (int)(t.chunk / (size_t)nchunks);
-        const float* inb = input + (size_t)b * N * C + c0 + (lane % LPR) * 4;
-        for (int j = 0; j < RW; j += RPI) {
-            const int i0 = wave * RW + j;
-            if (i0 >= U) break;
-            int rid = __builtin_amdgcn_readlane(ids, j);
-#pragma unroll
-            for (int q = 1; q < RPI; q++) {
-                const int rq = __builtin_amdgcn_readlane(ids, j + q);
-                rid = (lane / LPR) == q ? rq : rid;
-            }
-            const float* gp = inb + (size_t)rid * C;
-            float* lp = rows + ((size_t)buf * ucap + i0) * SLC;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                             (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
-        }
     };
 
     Tile t0 = next_tile();
-    Tile t1 = next_tile();
     int ids0 = ids_of(t0);
-    int ids1 = ids_of(t1);
-    unsigned rec0 = rec_of(t0);
-    issue_dma(t0, ids0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                          // filter + tile 0 in LDS
-
+    unsigned rc0[2] = {rec_of(t0, 0), rec_of(t0, 1)};
     const char* lrow = reinterpret_cast<const char*>(rows) + lane * (VEC * 4);
-    const float* lf = lfilt + lane * NO;
-    int buf = 0;
-    while (t0.valid) {
-        // ---- tile k+1: DMA into the other buffer; its records and tile k+2's row ids: loads in flight under the gather ----
-        issue_dma(t1, ids1, buf ^ 1);
-        Tile t2 = next_tile();
-        const int ids2 = ids_of(t2);
-        const unsigned rec1 = rec_of(t1);
+    const float* fl = lfilt + lane * NO;
+    constexpr int FST = SLC * R;                  // floats per filter row in LDS
 
-        // ---- gather tile k ----
-        const int T = (t0.a >> 8) & 0xff;
-        const int ns = t2_nsub(T);
-        const int j = ns == 4 ? wave >> 2 : (ns == 2 ? wave >> 1 : (ns == 1 ? wave : wave / 3));
-        const int sub = wave - j * ns;
-        const bool active = j < T && !(dbg & 2);
-        float acc[NO];
+    while (t0.valid) {
+        const int T = (t0.a >> 8) & 0xff, U = t0.a >> 16;
+        // ---- stage the tile's rows: LDS-DMA, RPI rows per wave instruction ----
+        if (!(dbg & 1)) {
+            const int RW = rows_per_wave(U);
+            const float* inb = input + (size_t)t0.b * N * C + c0 + (lane % LPR) * 4;
+            for (int j = 0; j < RW; j += RPI) {
+                const int i0 = wave * RW + j;
+                if (i0 >= U) break;
+                int rid = __builtin_amdgcn_readlane(ids0, j);
 #pragma unroll
-        for (int v = 0; v < NO; v++) acc[v] = 0.f;
-        int cnt = 0, m = 0;
-        if (active) {
-            cnt = __builtin_amdgcn_readlane((int)rec0, 48);
-            const int ng = __builtin_amdgcn_readlane((int)rec0, 49);
-            m = __builtin_amdgcn_readlane((int)rec0, 50);
-            const unsigned ew = (unsigned)__builtin_amdgcn_ds_bpermute((lane >> 2) << 2, (int)rec0);
-            const int eoff = (int)((ew >> ((lane & 3) * 8)) & 0xffu) * ROWB;
-            const unsigned gw = (unsigned)__builtin_amdgcn_ds_bpermute((16 + (lane >> 1)) << 2, (int)rec0);
-            const int grp = (int)((gw >> ((lane & 1) * 16)) & 0xffffu);
-            const int e0 = cnt * sub / ns, e1 = cnt * (sub + 1) / ns;
-            if (e0 < e1) {
-                const char* rb = lrow + (size_t)buf * ucap * ROWB;
-                int g = __popcll(__ballot(lane < ng && (grp & 0xff) <= e0));      // first group that ends after e0
-                int gd = __builtin_amdgcn_readlane(grp, g);
-                int gend = (gd & 0xff) < e1 ? (gd & 0xff) : e1;
-                wv_t wf = *reinterpret_cast<const wv_t*>(lf + (size_t)(gd >> 8) * (SLC * R));
-                int gd1 = __builtin_amdgcn_readlane(grp, (g + 1) & 63);
-                wv_t wn = *reinterpret_cast<const wv_t*>(lf + (size_t)(gd1 >> 8) * (SLC * R));
-                xv_t s = {};
-                for (int eb = e0; eb < e1; eb += 8) {
-                    xv_t x[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int k = (eb + u) < e1 ? (eb + u) : (e1 - 1);
-                        const int o = __builtin_amdgcn_readlane(eoff, k);
-                        x[u] = *reinterpret_cast<const xv_t*>(rb + o);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        if (eb + u < e1) {
-                            s += x[u];
-                            if (eb + u + 1 == gend) {
-                                if constexpr (VEC == 1) {
-                                    if constexpr (R == 1) acc[0] = fmaf(s, wf, acc[0]);
-                                    else {
-                                        acc[0] = fmaf(s, wf[0], acc[0]);
-                                        acc[1] = fmaf(s, wf[1], acc[1]);
-                                    }
-                                } else {
-#pragma unroll
-                                    for (int v = 0; v < NO; v++) acc[v] = fmaf(s[v / R], wf[v], acc[v]);
-                                }
-                                s = xv_t{};
-                                wf = wn;
-                                gd = gd1;
-                                gend = (gd & 0xff) < e1 ? (gd & 0xff) : e1;
-                                g++;
-                                gd1 = __builtin_amdgcn_readlane(grp, (g + 1) & 63);
-                                wn = *reinterpret_cast<const wv_t*>(lf + (size_t)(gd1 >> 8) * (SLC * R));
-                            }
-                        }
-                    }
+                for (int q = 1; q < RPI; q++) {
+                    const int rq = __builtin_amdgcn_readlane(ids0, j + q);     // rows past U: id 0 (a valid row, never read)
+                    rid = (lane / LPR) == q ? rq : rid;
                 }
-            }
-            if (sub > 0) {
-                wv_t pv;
-                if constexpr (NO == 1) pv = acc[0];
-                else {
-#pragma unroll
-                    for (int v = 0; v < NO; v++) pv[v] = acc[v];
-                }
-                *reinterpret_cast<wv_t*>(comb + (size_t)(j * (ns - 1) + sub - 1) * (64 * NO) + lane * NO) = pv;
+                const float* gp = inb + (size_t)rid * C;
+                float* lp = rows + (size_t)i0 * SLC;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                                 (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
             }
         }
+        // ---- in flight under the DMA: next tile's row ids and records, the first filter rows of this tile's targets ----
+        Tile t1 = next_tile();
+        const int ids1 = ids_of(t1);
+        const unsigned rn0 = rec_of(t1, 0), rn1 = rec_of(t1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (active && sub == 0) {
-            for (int q = 0; q < ns - 1; q++) {
-                const wv_t pv = *reinterpret_cast<const wv_t*>(comb + (size_t)(j * (ns - 1) + q) * (64 * NO) + lane * NO);
-                if constexpr (NO == 1) acc[0] += pv;
-                else {
+        // ---- gather from LDS: wave w takes targets w and w + 16 of the tile ----
 #pragma unroll
-                    for (int v = 0; v < NO; v++) acc[v] += pv[v];
+        for (int h = 0; h < 2; h++) {
+            const int jj = wave + kT2Waves * h;
+            if (jj >= T || (dbg & 2)) break;
+            const unsigned r0 = rc0[h];
+            const int cnt = __builtin_amdgcn_readlane((int)r0, 48);
+            const int m = __builtin_amdgcn_readlane((int)r0, 50);
+            // lane e <- slot byte of edge e (words 0..15), lane g <- group g (u16 in words 16..47)
+            const unsigned ew = (unsigned)__builtin_amdgcn_ds_bpermute((lane >> 2) << 2, (int)r0);
+            const int eoff = (int)((ew >> ((lane & 3) * 8)) & 0xffu) * ROWB;
+            const unsigned gw = (unsigned)__builtin_amdgcn_ds_bpermute((16 + (lane >> 1)) << 2, (int)r0);
+            const int grp = (int)((gw >> ((lane & 1) * 16)) & 0xffffu);
+            float acc[NO];
+#pragma unroll
+            for (int v = 0; v < NO; v++) acc[v] = 0.f;
+            int g = 0;
+            int gd = __builtin_amdgcn_readlane(grp, 0);
+            int gend = gd & 0xff;
+            wv_t wf = *reinterpret_cast<const wv_t*>(fl + (gd >> 8) * FST);
+            int gd1 = __builtin_amdgcn_readlane(grp, 1);
+            wv_t wn = *reinterpret_cast<const wv_t*>(fl + (gd1 >> 8) * FST);
+            xv_t s = {};
+            auto flush = [&]() {
+                t2_flush<R, VEC>(acc, s, wf);
+                s = xv_t{};
+                wf = wn;
+                gd = gd1;
+                gend = gd & 0xff;
+                g++;
+                gd1 = __builtin_amdgcn_readlane(grp, (g + 1) & 63);          // groups past the last: 0 -> bin 0, never used
+                wn = *reinterpret_cast<const wv_t*>(fl + (gd1 >> 8) * FST);
+            };
+            int eb = 0;
+            for (; eb + 8 <= cnt; eb += 8) {                                   // full batches: no bound tests
+                xv_t x[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int o = __builtin_amdgcn_readlane(eoff, eb + u);
+                    x[u] = *reinterpret_cast<const xv_t*>(lrow + o);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    s += x[u];
+                    if (eb + u + 1 == gend) flush();
+                }
+            }
+            if (eb < cnt) {                                                    // tail batch
+                xv_t x[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int k = (eb + u) < cnt ? (eb + u) : (cnt - 1);
+                    const int o = __builtin_amdgcn_readlane(eoff, k);
+                    x[u] = *reinterpret_cast<const xv_t*>(lrow + o);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (eb + u < cnt) {
+                        s += x[u];
+                        if (eb + u + 1 == gend) flush();
+                    }
                 }
             }
             const float fc = (float)cnt;
@@ -641,16 +472,13 @@ __global__ __launch_bounds__(1024) void dwconv_tile2p_fwd(
 #pragma unroll
                 for (int v = 0; v < NO; v++) o[v] = cnt > 0 ? acc[v] / fc : 0.f;
             }
-            const int b = (int)(t0.chunk / (size_t)nchunks);
-            *reinterpret_cast<wv_t*>(output + ((size_t)b * M + m) * CR + (size_t)(c0 + lane * VEC) * R) = o;
+            *reinterpret_cast<wv_t*>(output + ((size_t)t0.b * M + m) * CR + (size_t)(c0 + lane * VEC) * R) = o;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         t0 = t1;
-        t1 = t2;
-        ids1 = ids2;
-        rec0 = rec1;
-        buf ^= 1;
+        ids0 = ids1;
+        rc0[0] = rn0;
+        rc0[1] = rn1;
     }
 }
 
@@ -688,7 +516,7 @@ extern "C" int sph3d_tile2_plan(int B, int N, int M, int K, int F, int ucap, con
 {
     SPH3D_REQUIRE(B >= 0 && N > 0 && M > 0 && K > 0 && F > 0, "tile2_plan: bad dims B=%d N=%d M=%d K=%d F=%d", B, N, M, K, F);
     SPH3D_REQUIRE(K <= 64 && F <= 255 && N <= 65536, "tile2_plan: needs K <= 64, F <= 255, N <= 65536 (got K=%d F=%d N=%d)", K, F, N);
-    SPH3D_REQUIRE(ucap >= 64 && ucap <= 256 && ucap % 4 == 0, "tile2_plan: ucap=%d must be a multiple of 4 in [64, 256] (>= K rows so that one target always fits)", ucap);
+    SPH3D_REQUIRE(ucap >= 64 && ucap <= 256 && ucap % 4 == 0, "tile2_plan: ucap=%d must be a multiple of 4 in [64, 256] (>= K rows so that one target always fits; slots are bytes)", ucap);
     if (B == 0) return SPH3D_OK;
     const int nchunks = (M + kT2Chunk - 1) / kT2Chunk;
     const int W = (N + 31) >> 5;
@@ -706,12 +534,18 @@ extern "C" int sph3d_tile2_plan(int B, int N, int M, int K, int F, int ucap, con
 
 extern "C" int sph3d_depthwise_conv3d_tiled2_supported(int F, int C, int r, int K) { return t2_shape_ok(F, C, r, K) ? 1 : 0; }
 
-template <int R, int VEC, int UNR>
+static size_t t2_lds(int F, int C, int r, int ucap)
+{
+    const int SLC = C == 64 ? 64 : 128;
+    return sizeof(float) * ((size_t)ucap * SLC + (size_t)F * SLC * r);
+}
+
+template <int R, int VEC>
 static int launch_t2(int B, int N, int M, int F, int C, int ucap, const int* chdr, const unsigned* rec, const unsigned short* ulist,
                      const float* input, const float* filter, float* output, hipStream_t st)
 {
-    const size_t lds = (size_t)ucap * 64 * VEC * sizeof(float);
-    auto kern = dwconv_tile2_fwd<R, VEC, UNR>;
+    const size_t lds = t2_lds(F, C, R, ucap);
+    auto kern = dwconv_tile2_fwd<R, VEC>;
     if (lds > 48 * 1024) {
         int rc = check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                            "DepthwiseConv3dTiled2: hipFuncSetAttribute");
@@ -719,40 +553,10 @@ static int launch_t2(int B, int N, int M, int F, int C, int ucap, const int* chd
     }
     const int nchunks = (M + kT2Chunk - 1) / kT2Chunk;
     const int nslices = C / (64 * VEC);
-    if (t2_dbg() & 256) {
-        int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 512, lds);
-        fprintf(stderr, "tile2 fwd: lds %zu B, occupancy API says %d workgroups per CU\n", lds, nb);
-    }
-    hipLaunchKernelGGL(kern, dim3(xcd_grid(B, nchunks * nslices)), dim3(512), lds, st, B, N, M, F, C, nchunks, nslices, chdr, rec,
-                       ulist, input, filter, output, t2_dbg());
-    return check_launch("sph3d_depthwise_conv3d_tiled2");
-}
-
-#ifndef SPH3D_T2_UNR
-#define SPH3D_T2_UNR 2
-#endif
-
-static size_t t2p_lds(int F, int C, int r, int ucap)
-{
-    const int SLC = C == 64 ? 64 : 128;
-    const int NO = (SLC / 64) * r;
-    return sizeof(float) * ((size_t)2 * ucap * SLC + (size_t)F * SLC * r + (size_t)kT2CombSlots * 64 * NO);
-}
-
-template <int R, int VEC>
-static int launch_t2p(int B, int N, int M, int F, int C, int ucap, const int* chdr, const unsigned* rec, const unsigned short* ulist,
-                      const float* input, const float* filter, float* output, hipStream_t st)
-{
-    const size_t lds = t2p_lds(F, C, R, ucap);
-    auto kern = dwconv_tile2p_fwd<R, VEC>;
-    int rc = check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                       "DepthwiseConv3dTiled2: hipFuncSetAttribute");
-    if (rc) return rc;
-    const int nchunks = (M + kT2Chunk - 1) / kT2Chunk;
-    const int nslices = C / (64 * VEC);
-    hipLaunchKernelGGL(kern, dim3(256), dim3(1024), lds, st, B, N, M, F, C, nchunks, nslices, ucap, chdr, rec, ulist, input, filter,
-                       output, t2_dbg());
+    // one persistent workgroup per CU (rows of 512 B: ucap = 288 fills 144 KB of LDS); narrower rows leave room for two
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    hipLaunchKernelGGL(kern, dim3(256 * per_cu), dim3(1024), lds, st, B, N, M, F, C, nchunks, nslices, ucap, chdr, rec, ulist, input,
+                       filter, output, t2_dbg());
     return check_launch("sph3d_depthwise_conv3d_tiled2");
 }
 
@@ -768,17 +572,11 @@ extern "C" int sph3d_depthwise_conv3d_tiled2(int B, int N, int M, int F, int C, 
     if (B == 0) return SPH3D_OK;
     hipStream_t st = as_stream(stream);
     const int nsl = C == 64 ? 1 : C / 128;
-    if (!(t2_dbg() & 512) && t2p_lds(F, C, r, ucap) <= 160 * 1024 && nsl <= 32 && (32 % nsl) == 0) {
-        if (C == 64)
-            return r == 2 ? launch_t2p<2, 1>(B, N, M, F, C, ucap, chunk_hdr, records, row_lists, input, filter, output, st)
-                          : launch_t2p<1, 1>(B, N, M, F, C, ucap, chunk_hdr, records, row_lists, input, filter, output, st);
-        return r == 2 ? launch_t2p<2, 2>(B, N, M, F, C, ucap, chunk_hdr, records, row_lists, input, filter, output, st)
-                      : launch_t2p<1, 2>(B, N, M, F, C, ucap, chunk_hdr, records, row_lists, input, filter, output, st);
-    }
-    constexpr int U = SPH3D_T2_UNR;
+    SPH3D_REQUIRE(nsl <= 32 && (32 % nsl) == 0, "DepthwiseConv3dTiled2: %d channel slices do not divide the 32 workgroups of an XCD", nsl);
+    SPH3D_REQUIRE(t2_lds(F, C, r, ucap) <= 160 * 1024, "DepthwiseConv3dTiled2: ucap=%d rows + the filter slice do not fit the LDS", ucap);
     if (C == 64)
-        return r == 2 ? launch_t2<2, 1, U>(B, N, M, F, C, ucap, chunk_hdr, records, row_lists, input, filter, output, st)
-                      : launch_t2<1, 1, U>(B, N, M, F, C, ucap, chunk_hdr, records, row_lists, input, filter, output, st);
-    return r == 2 ? launch_t2<2, 2, U>(B, N, M, F, C, ucap, chunk_hdr, records, row_lists, input, filter, output, st)
-                  : launch_t2<1, 2, U>(B, N, M, F, C, ucap, chunk_hdr, records, row_lists, input, filter, output, st);
+        return r == 2 ? launch_t2<2, 1>(B, N, M, F, C, ucap, chunk_hdr, records, row_lists, input, filter, output, st)
+                      : launch_t2<1, 1>(B, N, M, F, C, ucap, chunk_hdr, records, row_lists, input, filter, output, st);
+    return r == 2 ? launch_t2<2, 2>(B, N, M, F, C, ucap, chunk_hdr, records, row_lists, input, filter, output, st)
+                  : launch_t2<1, 2>(B, N, M, F, C, ucap, chunk_hdr, records, row_lists, input, filter, output, st);
 }

@@ -32,8 +32,8 @@ for ucap in [int(u) for u in os.environ.get("UCAPS", "144").split(",")]:
         _plan.register_geometry(filt, xyz, xyz)
         t_plan = timeit(lambda: (_plan._fwd2.clear(), _plan.forward_plan2(idx, cnt, filt, F, ucap, use_order)), 10)
         chdr, rec, ulist, _ = _plan.forward_plan2(idx, cnt, filt, F, ucap, use_order)
-        nt = chdr.view(-1, 72)[:, 0].float()
-        a = chdr.view(-1, 72)[:, 1:65:2]
+        nt = chdr.view(-1, 136)[:, 0].float()
+        a = chdr.view(-1, 136)[:, 1:129:2]
         U = (a >> 16).float()
         T = ((a >> 8) & 0xff).float()
         msk = T > 0

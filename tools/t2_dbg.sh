@@ -1,3 +1,4 @@
 export TMPDIR=/tmp
-for d in 0 1 2 3; do echo "== dbg $d"; SPH3D_T2_DBG=$d UCAPS=112 timeout 100 python tools/exp_tile2.py 2>&1 | grep -E "order 1|C=" | head -4; done
-echo "== ucap 96"; UCAPS=96 timeout 100 python tools/exp_tile2.py 2>&1 | grep -E "order 1|C=" | head -4
+python tools/exp_fwd_variants.py 2>&1 | tail -1
+for v in w8s4 w8s8 w4s8 w16s4; do SPH3D_LIB=$PWD/sph3d_gcn_amd/csrc/libsph3d_$v.so python tools/exp_fwd_variants.py 2>&1 | tail -1; done
+python tools/exp_fwd_variants.py 2>&1 | tail -1
