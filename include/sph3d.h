@@ -88,6 +88,12 @@ int sph3d_build_sphere_graph(int B, int N, int M, int nn_sample, float radius, i
                              const float* database, const float* query,
                              int* nn_index, int* nn_count, float* nn_dist, int* filt_index,
                              void* transpose_workspace, size_t transpose_workspace_bytes, sph3d_stream_t stream);
+/* The same with ROCm's device-library atan2f for the bins (= sph3d_build_sphere_neighbor + sph3d_spherical_kernel_ocml:
+ * bit for bit the bins of the reference's own kernel built for this GPU; not reproducible on a CPU). */
+int sph3d_build_sphere_graph_ocml(int B, int N, int M, int nn_sample, float radius, int n, int p, int q,
+                             const float* database, const float* query,
+                             int* nn_index, int* nn_count, float* nn_dist, int* filt_index,
+                             void* transpose_workspace, size_t transpose_workspace_bytes, sph3d_stream_t stream);
 
 /* ---- buildkernel --------------------------------------------------------
  * replaces sphericalKernelLauncher (tf_ops/buildkernel/tf_buildkernel_gpu.cu:83-89;
@@ -321,28 +327,6 @@ int sph3d_elu_bn_backward(int R, int C, const float* y, const float* dout, const
                           const float* save_mean, const float* save_rstd, int training,
                           float* dy, float* dgamma, float* dbeta,
                           void* workspace, size_t workspace_bytes, sph3d_stream_t stream);
-
-/* ---- LDS-tiled depthwise convolution, second design (tile2.hip; round 3) ------------------------------
- * Same op as sph3d_depthwise_conv3d (replaces depthwiseConv3dLauncher, tf_ops/convolution/tf_conv3d_gpu.cu:107-113)
- * for a graph that has a tile plan.  The plan belongs to the graph, not to the convolution:
- *   sph3d_tile2_plan   one pass over (nn_index, nn_count, bin_index) of a graph with M output and N source points per
- *                      cloud (K <= 64, F <= 255, N <= 65536), in the processing order `order` (sph3d_spatial_order of
- *                      the output points' coordinates, or NULL = index order): chunks of 32 consecutive positions are
- *                      cut greedily into tiles of <= 16 targets whose distinct source rows number <= ucap (a multiple
- *                      of 4 in [64, 256]); per tile the row list, per target a 256-byte record with the LDS slot of
- *                      each edge (edges grouped by bin) and the (bin, end) of each group.  Sizes from
- *                      sph3d_tile2_plan_sizes (ints / 32-bit words / 16-bit entries).
- *   sph3d_depthwise_conv3d_tiled2   stages a tile's rows in LDS (ucap * min(C,128) * 4 bytes per workgroup) by LDS-DMA
- *                      and gathers from LDS; covers r in {1,2}, C = 64 or a multiple of 128.  Results equal
- *                      sph3d_depthwise_conv3d up to fp32 summation order. */
-int sph3d_tile2_plan_sizes(int B, int M, size_t* hdr_ints, size_t* rec_words, size_t* ulist_shorts);
-int sph3d_tile2_plan(int B, int N, int M, int K, int F, int ucap, const int* order, const int* nn_index,
-                     const int* nn_count, const int* bin_index, int* chunk_hdr, unsigned* records,
-                     unsigned short* row_lists, sph3d_stream_t stream);
-int sph3d_depthwise_conv3d_tiled2_supported(int F, int C, int r, int K);
-int sph3d_depthwise_conv3d_tiled2(int B, int N, int M, int F, int C, int r, int ucap, const int* chunk_hdr,
-                                  const unsigned* records, const unsigned short* row_lists, const float* input,
-                                  const float* filter, float* output, sph3d_stream_t stream);
 
 #ifdef __cplusplus
 }

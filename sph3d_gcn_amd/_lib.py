@@ -43,6 +43,7 @@ SIGNATURES = {
     "sph3d_graph_transpose_count": (_I, [_I] * 5 + [_P] * 3 + [_I, _P, _S, _P]),
     "sph3d_graph_transpose_finish": (_I, [_I] * 5 + [_P] * 8 + [_P, _S, _P]),
     "sph3d_build_sphere_graph": (_I, [_I, _I, _I, _I, _F, _I, _I, _I] + [_P] * 6 + [_P, _S, _P]),
+    "sph3d_build_sphere_graph_ocml": (_I, [_I, _I, _I, _I, _F, _I, _I, _I] + [_P] * 6 + [_P, _S, _P]),
     "sph3d_depthwise_conv3d_grad_t_workspace": (_S, [_I] * 5),
     "sph3d_depthwise_conv3d_grad_t": (_I, [_I] * 6 + [_P] * 10 + [_P, _S, _P]),
     "sph3d_spatial_order": (_I, [_I, _I, _P, _P, _P]),
@@ -51,10 +52,6 @@ SIGNATURES = {
     "sph3d_tile_plan": (_I, [_I] * 5 + [_P] * 11),
     "sph3d_depthwise_conv3d_tiled_supported": (_I, [_I] * 5),
     "sph3d_depthwise_conv3d_tiled": (_I, [_I] * 7 + [_P] * 11),
-    "sph3d_tile2_plan_sizes": (_I, [_I, _I, _P, _P, _P]),
-    "sph3d_tile2_plan": (_I, [_I] * 6 + [_P] * 8),
-    "sph3d_depthwise_conv3d_tiled2_supported": (_I, [_I] * 4),
-    "sph3d_depthwise_conv3d_tiled2": (_I, [_I] * 7 + [_P] * 7),
     "sph3d_scatter_grad_t": (_I, [_I] * 4 + [_P] * 6),
     "sph3d_scatter_grad_workspace": (_S, [_I] * 4),
     "sph3d_mean_interpolate": (_I, [_I] * 5 + [_P] * 5),

@@ -16,7 +16,6 @@ graph while its entry lives) and an event for consumers on other streams, like `
 """
 import collections
 import ctypes
-import os
 
 import torch
 
@@ -26,16 +25,13 @@ UCAP = 236            # rows a tile stages: (UCAP + 2) * 512 B of rows + the 33-
 MIN_POINTS = 64       # below this a level is a handful of tiles: the gather kernels are used
 _MAX_ENTRIES = 16
 
-UCAP2 = int(os.environ.get("SPH3D_T2_UCAP", "256"))   # tile2: rows a tile stages (x 512 B at C >= 128: two workgroups per CU)
-MIN_POINTS2 = 256
-
-_mode = "gather"      # "gather" | "tiled" | "tiled2": which forward kernel a convolution with a registered graph geometry uses
+_mode = "gather"      # "gather" | "tiled": which forward kernel a convolution with a registered graph geometry uses
 
 
 def set_mode(mode):
     global _mode
-    if mode not in ("gather", "tiled", "tiled2"):
-        raise ValueError("mode must be 'gather', 'tiled' or 'tiled2'")
+    if mode not in ("gather", "tiled"):
+        raise ValueError("mode must be 'gather' or 'tiled'")
     _mode = mode
 
 
@@ -50,11 +46,10 @@ def _ident(t):
 _geom = collections.OrderedDict()      # ident(bin_index) -> (database_xyz, query_xyz, bin_index)
 _orders = collections.OrderedDict()    # ident(xyz) -> entry
 _fwd = collections.OrderedDict()
-_fwd2 = collections.OrderedDict()
 
 
 def clear():
-    for d in (_geom, _orders, _fwd, _fwd2):
+    for d in (_geom, _orders, _fwd):
         d.clear()
 
 
@@ -142,38 +137,3 @@ def forward_plan(nn_index, nn_count, bin_index, F, ucap=None):
     k = (_ident(nn_index), _ident(nn_count), _ident(bin_index), F, tuple(nn_index.shape), ucap)
     return _entry(_fwd, k, build, (nn_index, nn_count, bin_index))
 
-
-# ---- second design (csrc/tile2.hip): greedy tiles, LDS-DMA staging --------------------------------------------------
-def applies2(N, M, K, F, C, r):
-    return (_mode == "tiled2" and K <= 64 and N <= 65536 and min(N, M) >= MIN_POINTS2
-            and bool(_lib.lib().sph3d_depthwise_conv3d_tiled2_supported(F, C, r, K)))
-
-
-def forward_plan2(nn_index, nn_count, bin_index, F, ucap=None, use_order=True):
-    """-> (chunk_hdr, records, row_lists, ucap) of include/sph3d.h: sph3d_tile2_plan, cached per graph; None when nobody
-    registered the coordinates of this graph (no spatial order to tile by)"""
-    g = _geom.get(_ident(bin_index))
-    if g is None:
-        return None
-    database, query = g[0], g[1]
-    ucap = UCAP2 if ucap is None else int(ucap)
-    B, M, K = nn_index.shape
-    if query.shape[1] != M:
-        return None
-    N = database.shape[1]
-
-    def build():
-        dev = nn_index.device
-        l = _lib.lib()
-        order = spatial_order(query) if use_order else None
-        sz = [ctypes.c_size_t() for _ in range(3)]
-        _lib.check(l.sph3d_tile2_plan_sizes(B, M, *[ctypes.byref(x) for x in sz]))
-        chdr = torch.empty((sz[0].value,), dtype=torch.int32, device=dev)
-        rec = torch.empty((sz[1].value,), dtype=torch.int32, device=dev)
-        ulist = torch.empty((sz[2].value,), dtype=torch.int16, device=dev)
-        _lib.check(l.sph3d_tile2_plan(B, N, M, K, F, ucap, _lib.ptr(order), _lib.ptr(nn_index), _lib.ptr(nn_count),
-                                      _lib.ptr(bin_index), _lib.ptr(chdr), _lib.ptr(rec), _lib.ptr(ulist), _lib.stream_ptr()))
-        return (chdr, rec, ulist, ucap)
-
-    k = (_ident(nn_index), _ident(nn_count), _ident(bin_index), F, tuple(nn_index.shape), ucap, bool(use_order))
-    return _entry(_fwd2, k, build, (nn_index, nn_count, bin_index))

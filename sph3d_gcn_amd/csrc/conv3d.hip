@@ -435,7 +435,8 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
 
     // COMPACT: lane i holds the bin of accumulator row i (one load for the whole launch; the per-segment scalar load of
     // activeBins[1 + fi] was not hoisted by the compiler and put an s_load + lgkmcnt(0) in front of every segment)
-    const int abv = COMPACT ? activeBins[1 + (lane < MAXF ? lane : 0)] : 0;
+    // (lanes >= A read entry 1, never past the A + 1 ints the list holds: the caller's tensor is F + 1 ints and F may be < MAXF)
+    const int abv = COMPACT ? activeBins[1 + ((lane < MAXF && lane < A) ? lane : 0)] : 0;
 
     // Work items of this XCD: (cloud, part) pairs dealt round-robin; a part is a contiguous range of POSITIONS in the
     // processing order (source_order, or the point index).  Wave gw visits positions gw, gw + stride, ...; the
@@ -496,7 +497,9 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
         const float sv = lane < cn ? svl : 0.f;
 #pragma unroll
         for (int fi = 0; fi < MAXF; fi++) {
-            if (fi < (COMPACT ? A : F) && ((nonempty >> fi) & 1ull)) {
+            // the mask exists for the compact table only (MAXF <= 64 there); the full table of the V = 2 plan has MAXF = 65 and a
+            // shift by 64 would be undefined — and let the compiler drop bin 64 altogether
+            if (fi < (COMPACT ? A : F) && (!COMPACT || ((nonempty >> (fi & 63)) & 1ull))) {
                 // COMPACT: row fi of the accumulators belongs to bin activeBins[1 + fi] (wave-uniform, F <= 63)
                 const int f = COMPACT ? __builtin_amdgcn_readlane(abv, fi) : fi;
                 const int a0 = COMPACT ? __builtin_amdgcn_readlane(ov0, f)

@@ -82,6 +82,7 @@ struct GraphFuse {
     int* deg;                // [B*N*F] segment counters (zeroed by the caller) or nullptr
     int* slotPos;            // [B*M*K]
     int* binUsed;            // [F]
+    int ocml;                // 1: the device library's atan2f (the reference as it builds here), 0: the shared correctly rounded one
 };
 
 template <int CPW, bool MULTI, bool DEFER, bool FUSE>
@@ -227,7 +228,9 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
                                     const float d2 = (dx * dx + dy * dy) + dz * dz;   // tf_nnquery_gpu.cu:45-46
                                     dist = sqrtf(sqrtf(d2));                          // :47 then :54 — sqrt of the distance
                                     if (FUSE) {
-                                        if (fx.filt != nullptr) bin = sphere_bin<false>(dx, dy, dz, dist, fx.radius, fx.n, fx.p, fx.q);
+                                        if (fx.filt != nullptr)
+                                            bin = fx.ocml ? sphere_bin<true>(dx, dy, dz, dist, fx.radius, fx.n, fx.p, fx.q)
+                                                          : sphere_bin<false>(dx, dy, dz, dist, fx.radius, fx.n, fx.p, fx.q);
                                         if (fx.deg != nullptr) {
                                             fx.slotPos[row * K + slot] = atomicAdd(&fx.deg[((size_t)i * N + id) * fx.F + bin], 1);
                                             fx.binUsed[bin] = 1;          // benign race: every writer stores 1
@@ -414,10 +417,10 @@ extern "C" int sph3d_graph_transpose_count(int B, int N, int M, int K, int F, co
                                            const int* bin_index, int want_active, void* workspace, size_t workspace_bytes,
                                            sph3d_stream_t stream);
 
-extern "C" int sph3d_build_sphere_graph(int B, int N, int M, int nn_sample, float radius, int n, int p, int q,
-                                        const float* database, const float* query,
-                                        int* nn_index, int* nn_count, float* nn_dist, int* filt_index,
-                                        void* transpose_workspace, size_t transpose_workspace_bytes, sph3d_stream_t stream)
+static int build_sphere_graph_impl(bool ocml, int B, int N, int M, int nn_sample, float radius, int n, int p, int q,
+                                   const float* database, const float* query,
+                                   int* nn_index, int* nn_count, float* nn_dist, int* filt_index,
+                                   void* transpose_workspace, size_t transpose_workspace_bytes, sph3d_stream_t stream)
 {
     // filt_index == NULL: no bins (an inter-level graph: one segment per source point), only the search and the counts
     const bool binned = filt_index != nullptr;
@@ -433,6 +436,7 @@ extern "C" int sph3d_build_sphere_graph(int B, int N, int M, int nn_sample, floa
     fx.n = n; fx.p = p; fx.q = q; fx.F = F;
     fx.radius = radius;
     fx.filt = filt_index;
+    fx.ocml = ocml ? 1 : 0;
     if (transpose_workspace != nullptr) {
         const size_t need = sph3d_graph_transpose_workspace(B, N, M, nn_sample, F);
         if (transpose_workspace_bytes < need) {
@@ -452,10 +456,30 @@ extern "C" int sph3d_build_sphere_graph(int B, int N, int M, int nn_sample, floa
     int rc = sphere_neighbor(0, B, N, M, nn_sample, radius, database, query, nn_index, nn_count, nn_dist, stream, &fx, &fused);
     if (rc || fused) return rc;
     // shapes whose hit lists do not fit LDS: the same results from the separate kernels
-    if (binned) rc = sph3d_spherical_kernel(B, N, M, nn_sample, n, p, q, radius, database, query, nn_index, nn_count, nn_dist, filt_index, stream);
+    if (binned)
+        rc = ocml ? sph3d_spherical_kernel_ocml(B, N, M, nn_sample, n, p, q, radius, database, query, nn_index, nn_count, nn_dist, filt_index, stream)
+                  : sph3d_spherical_kernel(B, N, M, nn_sample, n, p, q, radius, database, query, nn_index, nn_count, nn_dist, filt_index, stream);
     if (rc || transpose_workspace == nullptr) return rc;
     return sph3d_graph_transpose_count(B, N, M, nn_sample, F, nn_index, nn_count, filt_index, binned ? 1 : 0, transpose_workspace,
                                        transpose_workspace_bytes, stream);
+}
+
+extern "C" int sph3d_build_sphere_graph(int B, int N, int M, int nn_sample, float radius, int n, int p, int q,
+                                        const float* database, const float* query,
+                                        int* nn_index, int* nn_count, float* nn_dist, int* filt_index,
+                                        void* transpose_workspace, size_t transpose_workspace_bytes, sph3d_stream_t stream)
+{
+    return build_sphere_graph_impl(false, B, N, M, nn_sample, radius, n, p, q, database, query, nn_index, nn_count, nn_dist, filt_index,
+                                   transpose_workspace, transpose_workspace_bytes, stream);
+}
+
+extern "C" int sph3d_build_sphere_graph_ocml(int B, int N, int M, int nn_sample, float radius, int n, int p, int q,
+                                             const float* database, const float* query,
+                                             int* nn_index, int* nn_count, float* nn_dist, int* filt_index,
+                                             void* transpose_workspace, size_t transpose_workspace_bytes, sph3d_stream_t stream)
+{
+    return build_sphere_graph_impl(true, B, N, M, nn_sample, radius, n, p, q, database, query, nn_index, nn_count, nn_dist, filt_index,
+                                   transpose_workspace, transpose_workspace_bytes, stream);
 }
 
 extern "C" int sph3d_build_cube_neighbor(int B, int N, int M, int grid_size, int nn_sample, float length,

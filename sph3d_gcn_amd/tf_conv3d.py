@@ -48,14 +48,6 @@ def _depthwise_conv3d_impl(input: torch.Tensor, filter: torch.Tensor, nn_index: 
         out = _depthwise_conv3d_impl(Fn.pad(input, (0, pad)), Fn.pad(filter, (0, 0, 0, pad)), nn_index, nn_count, bin_index)
         return out[:, :, :C * r].contiguous()
     output = torch.empty((B, M, C * r), dtype=torch.float32, device=input.device)
-    plan2 = _plan.forward_plan2(nn_index, nn_count, bin_index, F) if _plan.applies2(N, M, K, F, C, r) else None
-    if plan2 is not None:
-        # LDS-tiled kernel, second design (csrc/tile2.hip): the graph's tile plan was built with the graph
-        chdr, rec, ulist, ucap = plan2
-        _lib.check(_lib.lib().sph3d_depthwise_conv3d_tiled2(
-            B, N, M, F, C, r, ucap, _lib.ptr(chdr), _lib.ptr(rec), _lib.ptr(ulist), _lib.ptr(input), _lib.ptr(filter),
-            _lib.ptr(output), _lib.stream_ptr()))
-        return output
     plan = _plan.forward_plan(nn_index, nn_count, bin_index, F) if _plan.applies(N, M, K, F, C, r) else None
     if plan is not None:
         # LDS-tiled kernel: the caller asked for it and the graph's tile plan can be built (coordinates registered)

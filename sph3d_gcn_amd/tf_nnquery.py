@@ -146,10 +146,13 @@ def build_sphere_graph(xyz, radius, nnsample, kernel, with_transpose=True):
     if with_transpose:
         wsb = l.sph3d_graph_transpose_workspace(B, N, N, K, F)
         ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
-    _lib.check(l.sph3d_build_sphere_graph(B, N, N, K, float(radius), n, p, q, _lib.ptr(xyz), _lib.ptr(xyz), _lib.ptr(nn_index),
-                                          _lib.ptr(nn_count), _lib.ptr(nn_dist), _lib.ptr(filt), _lib.ptr(ws), wsb,
-                                          _lib.stream_ptr()))
-    _plan.register_geometry(filt, xyz, xyz)
+    from . import tf_buildkernel
+    # tf_buildkernel.set_atan2("ocml") reaches the fused kernel too: the bins of the reference's own build, bit for bit
+    fn = l.sph3d_build_sphere_graph_ocml if tf_buildkernel._atan2 == "ocml" else l.sph3d_build_sphere_graph
+    _lib.check(fn(B, N, N, K, float(radius), n, p, q, _lib.ptr(xyz), _lib.ptr(xyz), _lib.ptr(nn_index),
+                  _lib.ptr(nn_count), _lib.ptr(nn_dist), _lib.ptr(filt), _lib.ptr(ws), wsb, _lib.stream_ptr()))
+    if _plan.get_mode() != "gather":
+        _plan.register_geometry(filt, xyz, xyz)
     if with_transpose:
         _tgraph.transpose(nn_index, nn_count, N, bin_index=filt, num_bins=F, counted_workspace=ws)
     return nn_index, nn_count, nn_dist, filt
