@@ -17,7 +17,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+# SPH3D_ORACLE_LIB: another build of the same source (the sanitizer build of `make -C oracle sanitize`)
+_LIB_PATH = os.environ.get("SPH3D_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -27,6 +28,8 @@ _ip = ctypes.POINTER(ctypes.c_int)
 
 def build(force=False, arch_flags=""):
     """Compile liboracle.so with gcc (seconds)."""
+    if os.environ.get("SPH3D_ORACLE_LIB"):
+        return _LIB_PATH
     src = os.path.join(_HERE, "sph3d_oracle.c")
     hdr = os.path.join(_HERE, "..", "include", "sph3d_atan2f.h")
     if (not force and os.path.exists(_LIB_PATH)

@@ -241,36 +241,56 @@ def sample_points(block, num_point, rng):
 
 def _rot_z(a):
     c, s = np.cos(a), np.sin(a)
-    return np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+    return np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]]).astype(np.float32)       # float32, like data_util.rot_z (:226-232)
 
 
-def _small_rotation(rng, sigma=0.06, clip=0.18):
-    ax, ay, az = np.clip(sigma * rng.randn(3), -clip, clip)
-    rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
-    ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
-    return _rot_z(az) @ ry @ rx
+def rotate_point_cloud(batch_xyz, rng, max_angle=2 * np.pi):
+    """utils/data_util.py:47-61: every cloud turned about the up (z) axis by its own uniform angle; float32 result.
+    One rng.uniform() per cloud, in order — the same draws as the reference makes from np.random."""
+    out = np.zeros(batch_xyz.shape, dtype=np.float32)
+    for k in range(batch_xyz.shape[0]):
+        out[k, ...] = np.dot(batch_xyz[k, ...].reshape((-1, 3)), _rot_z(rng.uniform() * max_angle))
+    return out
+
+
+def rotate_perturbation_point_cloud(batch_xyz, rng, angle_sigma=0.06, angle_clip=0.18):
+    """utils/data_util.py:140-163: a small random rotation Rz Ry Rx per cloud (three clipped normal angles); float32 result"""
+    out = np.zeros(batch_xyz.shape, dtype=np.float32)
+    for k in range(batch_xyz.shape[0]):
+        ax, ay, az = np.clip(angle_sigma * rng.randn(3), -angle_clip, angle_clip)
+        rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+        ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+        rz = np.array([[np.cos(az), -np.sin(az), 0], [np.sin(az), np.cos(az), 0], [0, 0, 1]])
+        out[k, ...] = np.dot(batch_xyz[k, ...].reshape((-1, 3)), np.dot(rz, np.dot(ry, rx)))
+    return out
+
+
+def jitter_point_cloud(batch_xyz, rng, sigma=0.01, clip=0.02):
+    """utils/data_util.py:166-176: per-point normal noise clipped at `clip`; float64 result (noise + data)"""
+    noise = np.clip(sigma * rng.randn(*batch_xyz.shape), -1 * clip, clip)
+    noise += batch_xyz
+    return noise
 
 
 def augment_batch(batch_input, batch_label, batch_inner, rng):
-    """train_s3dis.py:116-141: shuffle the blocks of the batch, shuffle the point order (the same permutation for every
-    block), rotate the first third about z by a uniform angle then by a small random rotation, jitter the second third
-    (sigma 0.01, clipped at 0.02); colours, labels and the last third are left alone."""
+    """train_s3dis.py:114-142, draw for draw: shuffle the blocks of the batch, shuffle the point order (the same permutation
+    for every block), turn the first third about z by a uniform angle and then by a small random rotation, jitter the
+    second third (sigma 0.01, clipped at 0.02); colours, labels and the last third are left alone.  With
+    rng = np.random.RandomState(s) the result equals the reference's under np.random.seed(s), bit for bit
+    (tests/golden/blockio_ref.npz); the arithmetic runs in the reference's precisions (float64 batch, float32 rotations)
+    and the float32 batch the training step consumes is the final cast."""
     bsize, num_point, _ = batch_input.shape
-    order = rng.permutation(bsize)
+    order = rng.permutation(bsize)                      # == np.random.shuffle(np.arange(bsize))
     batch_input, batch_label, batch_inner = batch_input[order], batch_label[order], batch_inner[order]
     perm = rng.permutation(num_point)
     batch_input, batch_label, batch_inner = batch_input[:, perm], batch_label[:, perm], batch_inner[:, perm]
-    batch_input = np.array(batch_input, dtype=np.float32, copy=True)
+    batch_input = np.array(batch_input, dtype=np.float64, copy=True)      # the training loop's batch is float64 (:328)
     third = int(np.int32(1 / 3.0 * bsize))
-    for k in range(third):
-        xyz = batch_input[k, :, 0:3].astype(np.float64)
-        xyz = xyz @ _rot_z(rng.uniform() * 2 * np.pi)
-        xyz = xyz @ _small_rotation(rng)
-        batch_input[k, :, 0:3] = xyz.astype(np.float32)
-    if third:
-        noise = np.clip(0.01 * rng.randn(third, num_point, 3), -0.02, 0.02)
-        batch_input[third:2 * third, :, 0:3] += noise.astype(np.float32)
-    return batch_input, batch_label, batch_inner
+    xyz = rotate_point_cloud(batch_input[0:third, :, 0:3], rng)
+    xyz = rotate_perturbation_point_cloud(xyz, rng)
+    batch_input[0:third, :, 0:3] = xyz
+    batch_input[third:2 * third, :, 0:3] = jitter_point_cloud(batch_input[third:2 * third, :, 0:3], rng)
+    return batch_input.astype(np.float32), batch_label, batch_inner
 
 
 def training_batches(paths, batch_size, num_point, rng, augment=True, shuffle_buffer=10000):

@@ -169,3 +169,51 @@ def test_training_batches_epoch(tmp_path):
     assert [g[0].shape[0] for g in got] == [2, 2, 1]
     for x, l, i in got:
         assert x.shape[1:] == (2048, 6) and l.shape[1] == 2048 and set(np.unique(i)) <= {0, 1} and l.min() >= 0 and l.max() < 13
+
+
+# ---- pins against the reference's own numpy (tests/golden/make_blockio_golden.py imports /root/reference in the build
+# ---- container; only its inputs / outputs are committed) ---------------------------------------------------------
+def _golden():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "blockio_ref.npz"))
+
+
+def _same(a, b):
+    """bit for bit on this build; a BLAS that fuses the 3-term dot products differently may move a float by one ulp"""
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype
+    if not np.array_equal(a, b):
+        np.testing.assert_array_max_ulp(a, b, maxulp=1)
+
+
+def test_augmentation_primitives_equal_the_reference_numpy():
+    g = _golden()
+    xyz = g["xyz"]
+    for name in ("rotate_point_cloud", "rotate_perturbation_point_cloud", "jitter_point_cloud"):
+        rng = np.random.RandomState(int(g[name + "_seed"]))       # same MT19937 stream as np.random.seed(seed)
+        _same(getattr(blockio, name)(xyz.copy(), rng), g[name])
+
+
+def test_augment_batch_equals_the_reference_augment_fn():
+    g = _golden()
+    rng = np.random.RandomState(int(g["aug_seed"]))
+    x, l, i = blockio.augment_batch(g["aug_in_input"].copy(), g["aug_in_label"].copy(), g["aug_in_inner"].copy(), rng)
+    np.testing.assert_array_equal(l, g["aug_out_label"])
+    np.testing.assert_array_equal(i, g["aug_out_inner"])
+    assert x.dtype == np.float32
+    _same(x, g["aug_out_input"].astype(np.float32))             # the float32 feed of the reference's float64 batch
+    # the draws really were consumed in the reference's order: the stream is at the same position afterwards
+    np.random.seed(int(g["aug_seed"]))
+    ref_rng = np.random.RandomState(int(g["aug_seed"]))
+    blockio.augment_batch(g["aug_in_input"].copy(), g["aug_in_label"].copy(), g["aug_in_inner"].copy(), ref_rng)
+    assert ref_rng.randint(1 << 30) == rng.randint(1 << 30)
+
+
+def test_block_sampling_rule_equals_the_reference_draws():
+    g = _golden()
+    rng = np.random.RandomState(int(g["sample_seed"]))
+    big = np.arange(1000 * 8, dtype=np.float32).reshape(1000, 8)
+    small = np.arange(120 * 8, dtype=np.float32).reshape(120, 8)
+    x, _, _ = blockio.sample_points(big, 300, rng)
+    np.testing.assert_array_equal(x[:, 0] / 8, g["sample_300_of_1000"])       # row ids: without replacement
+    x, _, _ = blockio.sample_points(small, 300, rng)
+    np.testing.assert_array_equal(x[:, 0] / 8, g["sample_300_of_120"])        # too few points: with replacement
