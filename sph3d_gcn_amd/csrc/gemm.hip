@@ -174,10 +174,14 @@ struct Stage {
 // A(m,k): AK ? A[m*lda + k] : A[k*lda + m].   B(k,n): BKM ? B[n*ldb + k] : B[k*ldb + n].
 // 128x128 / BK = 16 unguarded tiles: 124 VGPRs and 40 KB of LDS -> FOUR workgroups per CU, so the common grids of
 // 1024 / 2048 tiles have no partial last wave of workgroups (3 per CU left a quarter of the run at 1/3 occupancy).
-template <bool AK, bool BKM, int BMT, int BN, int BK, bool SPLITK, bool GUARD>
+// STATS (forward product of a layer whose tail is ELU -> batch norm, utils/sph3gcn_util.py:152-161): the epilogue also emits,
+// per half tile of rows and per column, sum z and sum z*z with z = elu(y) — the partial sums the fused ELU+BN op's statistics
+// pass would otherwise produce by reading Y once more (norm.hip: norm_reduce_kernel, same [block][2][C] layout).
+template <bool AK, bool BKM, int BMT, int BN, int BK, bool SPLITK, bool GUARD, bool STATS = false>
 __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? 4 : 2) void gemm_f32_mfma(int M, int N, int Kd, const float* __restrict__ A, int lda,
                                                      const float* __restrict__ B, int ldb, float* __restrict__ Cmat,
-                                                     int ldc, const float* __restrict__ bias, int act, int kchunk)
+                                                     int ldc, const float* __restrict__ bias, int act, int kchunk,
+                                                     float* __restrict__ stats = nullptr)
 {
     using SA = Stage<AK, BMT, BK>;
     using SB = Stage<BKM, BN, BK>;
@@ -284,6 +288,31 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? 4 : 2) void gemm_f32_mf
         float* stage = lds + wave * (32 * EP);
         constexpr int LPR = WN / 4;                          // lanes per row
         constexpr int RPI = 64 / LPR;                        // rows per store instruction
+        if constexpr (STATS) {
+            // a lane's 16 x TM values of column block j all sit in ONE column (col = lane & 31): sum, fold the two lane halves,
+            // one store per (row half of the tile, column); fixed order, no atomics
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const float bv = bias != nullptr ? bias[n0 + wn + j * 32 + li] : 0.f;
+                float sz = 0.f, sq = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const float y = acc[i][j][e] + bv;
+                        const float z = y > 0.f ? y : __expf(y) - 1.f;         // == norm.hip: elu1
+                        sz += z;
+                        sq = fmaf(z, z, sq);
+                    }
+                sz += __shfl_xor(sz, 32);
+                sq += __shfl_xor(sq, 32);
+                if (lk == 0) {
+                    float* sp = stats + (size_t)(tm * 2 + (wave >> 1)) * 2 * N + n0 + wn + j * 32 + li;
+                    sp[0] = sz;
+                    sp[N] = sq;
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; i++) {
 #pragma unroll
@@ -401,6 +430,19 @@ static int launch_gemm(int M, int N, int Kd, const float* A, int lda, const floa
     return check_launch("sph3d_pointwise_gemm");
 }
 
+// forward product + BN partial statistics: unguarded NN tiles only.  -> row blocks of the statistics (2 per tile row), 0 if
+// the shape does not qualify (the caller then runs the plain product and the op's own statistics pass)
+static int nn_stats_tile(int M, int N, int Kd, int& bm, int& bn)
+{
+    const bool whole = (M % 128 == 0) && (N % 64 == 0) && (N <= 64 || N % 128 == 0) && (Kd % BKS == 0) && (Kd % 4 == 0) && (N % 4 == 0);
+    if (!whole) return 0;
+    auto ntiles = [&](int a, int b) { return (long long)((M + a - 1) / a) * ((N + b - 1) / b); };
+    if (N > 64 && ntiles(128, 128) >= 512) { bm = 128; bn = 128; }
+    else if (N <= 64 && ntiles(128, 64) >= 512) { bm = 128; bn = 64; }
+    else { bm = 64; bn = 64; }
+    return 2 * (M / bm);
+}
+
 // split-K plan for the weight gradient: enough (tile, split) workgroups to fill 256 CUs, k chunks multiple of BK
 static void tn_plan(int R, int Cin, int Cout, int& bn, int& tiles, int& nsplit, int& kchunk)
 {
@@ -433,6 +475,36 @@ extern "C" int sph3d_pointwise_gemm(int R, int Cin, int Cout, const float* X, co
     // Y[R,Cout] = X[R,Cin] * op(W);  trans_w: W is stored [Cout,Cin] (k contiguous), else [Cin,Cout] (n contiguous)
     if (trans_w) return launch_gemm<true, true>(R, Cout, Cin, X, Cin, W, Cin, Y, Cout, bias, act, st);
     return launch_gemm<true, false>(R, Cout, Cin, X, Cin, W, Cout, Y, Cout, bias, act, st);
+}
+
+extern "C" int sph3d_pointwise_gemm_bnstats_blocks(int R, int Cin, int Cout)
+{
+    int bm = 0, bn = 0;
+    return (R > 0 && Cin > 0 && Cout > 0) ? nn_stats_tile(R, Cout, Cin, bm, bn) : 0;
+}
+
+extern "C" int sph3d_pointwise_gemm_bnstats(int R, int Cin, int Cout, const float* X, const float* W, float* Y, float* partial,
+                                            sph3d_stream_t stream)
+{
+    SPH3D_REQUIRE(R > 0 && Cin > 0 && Cout > 0, "pointwise_gemm_bnstats: bad dims R=%d Cin=%d Cout=%d", R, Cin, Cout);
+    int bm = 0, bn = 0;
+    const int nblk = nn_stats_tile(R, Cout, Cin, bm, bn);
+    if (nblk == 0 || !aligned16(X) || !aligned16(W) || !aligned16(Y)) {
+        set_error("pointwise_gemm_bnstats: shape (%d, %d -> %d) needs whole tiles and 16-byte aligned operands", R, Cin, Cout);
+        return SPH3D_EUNSUPPORTED;
+    }
+    hipStream_t st = as_stream(stream);
+    const unsigned tiles = (unsigned)((R / bm) * (Cout / bn));
+    if (bm == 128 && bn == 128)
+        hipLaunchKernelGGL((gemm_f32_mfma<true, false, 128, 128, BKS, false, false, true>), dim3(tiles), dim3(256), 0, st, R, Cout, Cin, X,
+                           Cin, W, Cout, Y, Cout, nullptr, 0, 0, partial);
+    else if (bm == 128)
+        hipLaunchKernelGGL((gemm_f32_mfma<true, false, 128, 64, BKS, false, false, true>), dim3(tiles), dim3(256), 0, st, R, Cout, Cin, X,
+                           Cin, W, Cout, Y, Cout, nullptr, 0, 0, partial);
+    else
+        hipLaunchKernelGGL((gemm_f32_mfma<true, false, 64, 64, BKS, false, false, true>), dim3(tiles), dim3(256), 0, st, R, Cout, Cin, X,
+                           Cin, W, Cout, Y, Cout, nullptr, 0, 0, partial);
+    return check_launch("sph3d_pointwise_gemm_bnstats");
 }
 
 extern "C" size_t sph3d_pointwise_gemm_tn_workspace(int R, int Cin, int Cout)

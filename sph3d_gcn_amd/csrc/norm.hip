@@ -270,6 +270,25 @@ extern "C" int sph3d_elu_bn_forward(int R, int C, const float* y, const float* g
     return check_launch("sph3d_elu_bn_forward");
 }
 
+// The same op when the statistics' partial sums already exist (sph3d_pointwise_gemm_bnstats wrote them from the GEMM's
+// epilogue: partial[nblk][2][C] = per row block sum elu(y), sum elu(y)^2): finalize + apply only, training mode.
+extern "C" int sph3d_elu_bn_forward_partials(int R, int C, int nblk, const float* partial, const float* y, const float* gamma,
+                                             const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                             float* out, float* save_mean, float* save_rstd, sph3d_stream_t stream)
+{
+    SPH3D_REQUIRE(R > 0 && C > 0 && C % 4 == 0 && C <= 1024 && nblk > 0, "elu_bn_partials: needs R>0, C%%4==0, C<=1024, nblk>0 (got R=%d C=%d nblk=%d)",
+                  R, C, nblk);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(norm_fwd_finalize, dim3((C + 31) / 32), dim3(32 * kFinLanes), 0, st, R, C, nblk, partial, eps, momentum,
+                       save_mean, save_rstd, running_mean, running_var);
+    const long long total4 = (long long)R * C / 4;
+    long long blocks = (total4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(norm_apply_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, total4, C, y, nullptr, save_mean,
+                       save_rstd, gamma, beta, nullptr, out);
+    return check_launch("sph3d_elu_bn_forward_partials");
+}
+
 extern "C" int sph3d_elu_bn_backward(int R, int C, const float* y, const float* dout, const float* gamma,
                                      const float* save_mean, const float* save_rstd, int training,
                                      float* dy, float* dgamma, float* dbeta,

@@ -235,6 +235,26 @@ def _finish(outputs, num_out_channels, scope, activation_fn, with_bn, with_bias,
     return outputs
 
 
+def _fused_tail_applies(x2d, num_out_channels, activation_fn, with_bn, with_bias, is_training):
+    """GEMM + ELU + batch norm with the statistics in the GEMM's epilogue (tf_norm.gemm_elu_batch_norm): training mode, no
+    bias, shapes the statistics kernel covers"""
+    training = True if is_training is None else bool(is_training)
+    return (FUSE_GEMM_BN and FUSE_ELU_BN and with_bn and not with_bias and activation_fn is elu and training and x2d.is_cuda
+            and tf_norm.supported(num_out_channels)
+            and tf_norm.gemm_bn_blocks(x2d.shape[0], x2d.shape[1], num_out_channels) > 0)
+
+
+def _gemm_tail(x2d, kernel, out_shape, num_out_channels, scope, activation_fn, with_bn, with_bias, reuse, is_training):
+    """tf.matmul -> (+ biases) -> activation -> batch norm of the three layer kinds (utils/sph3gcn_util.py:146-161,204-222,260-273)"""
+    if _fused_tail_applies(x2d, num_out_channels, activation_fn, with_bn, with_bias, is_training):
+        store = get_variable_store()
+        gamma, beta, moving_mean, moving_var = _bn_variables(store, scope + '/bn', num_out_channels)
+        out = tf_norm.gemm_elu_batch_norm(x2d, kernel, gamma, beta, moving_mean, moving_var)
+        return out.reshape(out_shape)
+    outputs = tf_gemm.matmul(x2d, kernel).reshape(out_shape)
+    return _finish(outputs, num_out_channels, scope, activation_fn, with_bn, with_bias, reuse, is_training)
+
+
 def separable_conv3d(inputs,
                      num_out_channels,
                      kernel_size,
@@ -265,10 +285,8 @@ def separable_conv3d(inputs,
     kernel = _variable_with_weight_decay(scope + '/weights', shape=[num_in_channels, num_out_channels],
                                          use_xavier=use_xavier, stddev=stddev, with_decay=weight_decay)
     # pointwise convolution as one GEMM over all points
-    outputs = outputs.reshape(-1, num_in_channels)
-    outputs = tf_gemm.matmul(outputs, kernel)
-    outputs = outputs.reshape(batch_size, -1, num_out_channels)
-    return _finish(outputs, num_out_channels, scope, activation_fn, with_bn, with_bias, reuse, is_training)
+    return _gemm_tail(outputs.reshape(-1, num_in_channels), kernel, (batch_size, -1, num_out_channels), num_out_channels, scope,
+                      activation_fn, with_bn, with_bias, reuse, is_training)
 
 
 def pointwise_conv3d(inputs,
@@ -287,9 +305,8 @@ def pointwise_conv3d(inputs,
     num_in_channels = inputs.shape[-1]
     kernel = _variable_with_weight_decay(scope + '/weights', shape=[num_in_channels, num_out_channels],
                                          use_xavier=use_xavier, stddev=stddev, with_decay=weight_decay)
-    outputs = tf_gemm.matmul(inputs.reshape(-1, num_in_channels), kernel)
-    outputs = outputs.reshape(batch_size, -1, num_out_channels)
-    return _finish(outputs, num_out_channels, scope, activation_fn, with_bn, with_bias, reuse, is_training)
+    return _gemm_tail(inputs.reshape(-1, num_in_channels), kernel, (batch_size, -1, num_out_channels), num_out_channels, scope,
+                      activation_fn, with_bn, with_bias, reuse, is_training)
 
 
 def fully_connected(inputs,
@@ -337,6 +354,7 @@ def unpool3d(inputs, nn_index, nn_count, nn_dist, scope, method):
     return outputs
 
 
+FUSE_GEMM_BN = True    # the statistics of that tail from the GEMM's epilogue where the shape allows (tf_norm.gemm_elu_batch_norm)
 FUSE_ELU_BN = True     # fused sph3d::elu_bn for the ELU -> BN tail (same variables / moving statistics as the unfused ops)
 
 

@@ -90,3 +90,83 @@ class _EluBnFn(torch.autograd.Function):
 
 def elu_batch_norm(y, gamma, beta, moving_mean, moving_var, training=True):
     return _EluBnFn.apply(y, gamma, beta, moving_mean, moving_var, bool(training))
+
+
+# ---- layer tail with the statistics in the GEMM's epilogue (first half) ---------------------------------
+def gemm_bn_blocks(R, Cin, Cout):
+    """row blocks of partial statistics sph3d_pointwise_gemm_bnstats writes for this shape; 0 = shape not covered"""
+    return int(_lib.lib().sph3d_pointwise_gemm_bnstats_blocks(int(R), int(Cin), int(Cout)))
+
+
+def _gemm_bnstats_impl(x: torch.Tensor, w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """y[R,Cout] = x @ w and partial[nblk, 2, Cout] = per row block (sum elu(y), sum elu(y)^2)"""
+    _lib.require_device(x, w)
+    x, w = _lib.f32(x), _lib.f32(w)
+    R, Cin = x.shape
+    Cout = w.shape[1]
+    nblk = gemm_bn_blocks(R, Cin, Cout)
+    if nblk == 0:
+        raise ValueError("pointwise_gemm_bnstats: shape (%d, %d -> %d) is not covered (whole tiles needed)" % (R, Cin, Cout))
+    y = torch.empty((R, Cout), dtype=torch.float32, device=x.device)
+    partial = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().sph3d_pointwise_gemm_bnstats(R, Cin, Cout, _lib.ptr(x), _lib.ptr(w), _lib.ptr(y), _lib.ptr(partial),
+                                                        _lib.stream_ptr()))
+    return y, partial
+
+
+def _elu_bn_partials_impl(y: torch.Tensor, partial: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                          moving_mean: torch.Tensor, moving_var: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """training-mode elu_bn whose statistics come from `partial` instead of a pass over y"""
+    _lib.require_device(y, partial, gamma, beta, moving_mean, moving_var)
+    y, partial = _lib.f32(y), _lib.f32(partial)
+    C = y.shape[-1]
+    R = y.numel() // C
+    out = torch.empty_like(y)
+    save_mean = torch.empty((C,), dtype=torch.float32, device=y.device)
+    save_rstd = torch.empty((C,), dtype=torch.float32, device=y.device)
+    _lib.check(_lib.lib().sph3d_elu_bn_forward_partials(R, C, partial.shape[0], _lib.ptr(partial), _lib.ptr(y), _lib.ptr(gamma),
+                                                         _lib.ptr(beta), _lib.ptr(moving_mean), _lib.ptr(moving_var),
+                                                         1.0 - MOMENTUM, EPSILON, _lib.ptr(out), _lib.ptr(save_mean),
+                                                         _lib.ptr(save_rstd), _lib.stream_ptr()))
+    return out, save_mean, save_rstd
+
+
+_gemm_bnstats = torch.library.custom_op("sph3d::pointwise_gemm_bnstats", mutates_args=())(_gemm_bnstats_impl)
+_elu_bn_partials = torch.library.custom_op("sph3d::elu_bn_partials", mutates_args=("moving_mean", "moving_var"))(_elu_bn_partials_impl)
+
+
+@_gemm_bnstats.register_fake
+def _(x, w):
+    nblk = gemm_bn_blocks(x.shape[0], x.shape[1], w.shape[1])
+    return x.new_empty((x.shape[0], w.shape[1])), x.new_empty((nblk, 2, w.shape[1]))
+
+
+@_elu_bn_partials.register_fake
+def _(y, partial, gamma, beta, moving_mean, moving_var):
+    return torch.empty_like(y), torch.empty_like(gamma), torch.empty_like(gamma)
+
+
+class _GemmEluBnFn(torch.autograd.Function):
+    """out = batch_norm(elu(x @ w)) in training mode: GEMM (statistics in its epilogue) -> finalize -> apply.  Saves the raw
+    product y; the backward is elu_bn's followed by the GEMM's two gradient products."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, moving_mean, moving_var):
+        y, partial = _gemm_bnstats_impl(x, w)
+        out, save_mean, save_rstd = _elu_bn_partials_impl(y, partial, gamma, beta, moving_mean, moving_var)
+        ctx.save_for_backward(x, w, y, gamma, save_mean, save_rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import tf_gemm
+        x, w, y, gamma, save_mean, save_rstd = ctx.saved_tensors
+        dy, dgamma, dbeta = _bwd_impl(y, dout, gamma, save_mean, save_rstd, True)
+        dx = tf_gemm._pointwise_gemm_impl(dy, w, True) if ctx.needs_input_grad[0] else None
+        dw = tf_gemm._pointwise_gemm_tn_impl(x, dy) if ctx.needs_input_grad[1] else None
+        return dx, dw, dgamma, dbeta, None, None
+
+
+def gemm_elu_batch_norm(x, w, gamma, beta, moving_mean, moving_var):
+    """x[R,Cin] @ w[Cin,Cout] -> ELU -> batch norm (training statistics), one fused tail"""
+    return _GemmEluBnFn.apply(x, w, gamma, beta, moving_mean, moving_var)

@@ -219,3 +219,62 @@ def test_scannet_shaped_full_step_65536(dev, mode):
               % (mode, dt * 1e3, (time.perf_counter() - t0) * 1e3))
     finally:
         tf_nnquery.set_radius_mode("compat")
+
+
+@pytest.mark.parametrize("R,Cin,Cout", [(131072, 128, 128), (32768, 256, 256), (6144, 512, 512), (2048, 1024, 512), (131072, 16, 64),
+                                        (12288, 1024, 256), (768, 64, 64)])
+def test_gemm_with_bn_statistics_epilogue_vs_reference(dev, R, Cin, Cout):
+    """SURVEY 8f.3 (first half): x @ w -> ELU -> batch norm with the statistics' partial sums from the GEMM's epilogue ==
+    the same tail in float64 torch (utils/sph3gcn_util.py:146-161 semantics: ELU, then tf.layers.batch_normalization with
+    momentum 0.99 / epsilon 1e-3, biased variance into the moving statistics) and == the unfused HIP ops"""
+    from sph3d_gcn_amd import tf_norm, tf_gemm
+    assert tf_norm.gemm_bn_blocks(R, Cin, Cout) > 0
+    g = torch.Generator().manual_seed(R + Cin)
+    x = (torch.randn(R, Cin, generator=g) * 0.5).to(dev)
+    w = (torch.randn(Cin, Cout, generator=g) / Cin ** 0.5).to(dev)
+    gamma = (1.0 + 0.1 * torch.randn(Cout, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(Cout, generator=g)).to(dev)
+    dout = torch.randn(R, Cout, generator=g).to(dev)
+
+    def run(fn):
+        xs, ws, gs, bs = (t.clone().requires_grad_(True) for t in (x, w, gamma, beta))
+        mm, mv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+        out = fn(xs, ws, gs, bs, mm, mv)
+        out.backward(dout)
+        return [out.detach(), xs.grad, ws.grad, gs.grad, bs.grad, mm, mv]
+
+    fused = run(lambda a, b, c, d, mm, mv: tf_norm.gemm_elu_batch_norm(a, b, c, d, mm, mv))
+    plain = run(lambda a, b, c, d, mm, mv: tf_norm.elu_batch_norm(tf_gemm.matmul(a, b), c, d, mm, mv, True))
+
+    def ref(a, b, c, d, mm, mv):
+        a, b, c, d = a.double(), b.double(), c.double(), d.double()
+        z = torch.nn.functional.elu(a @ b)
+        mean, var = z.mean(0), z.var(0, unbiased=False)
+        mm.mul_(0.99).add_(mean.detach().float(), alpha=0.01)
+        mv.mul_(0.99).add_(var.detach().float(), alpha=0.01)
+        return ((z - mean) / torch.sqrt(var + 1e-3) * c + d).float()
+
+    want = run(ref)
+    names = ["out", "dx", "dw", "dgamma", "dbeta", "moving_mean", "moving_var"]
+    for nm, f, p, r in zip(names, fused, plain, want):
+        scale = max(1.0, float(r.abs().max()))
+        tol = 2e-5 if nm in ("dw", "dgamma", "dbeta") else 1e-5          # sums over up to 131 072 rows of fp32 products
+        np.testing.assert_allclose(_n(f) / scale, _n(r) / scale, rtol=tol, atol=tol, err_msg=nm)
+        np.testing.assert_allclose(_n(f) / scale, _n(p) / scale, rtol=tol, atol=tol, err_msg=nm + " (vs unfused HIP ops)")
+
+
+def test_gemm_bnstats_ops_registered(dev):
+    from sph3d_gcn_amd import tf_norm
+    x = torch.randn(1024, 64, device=dev)
+    w = torch.randn(64, 128, device=dev)
+    torch.library.opcheck(torch.ops.sph3d.pointwise_gemm_bnstats, (x, w), test_utils=("test_schema", "test_faketensor"))
+    y, partial = torch.ops.sph3d.pointwise_gemm_bnstats(x, w)
+    z = torch.nn.functional.elu(y.double())
+    np.testing.assert_allclose(_n(partial[:, 0].double().sum(0)), _n(z.sum(0)), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(_n(partial[:, 1].double().sum(0)), _n((z * z).sum(0)), rtol=1e-5, atol=1e-3)
+    assert partial.shape == (tf_norm.gemm_bn_blocks(1024, 64, 128), 2, 128)
+    gamma, beta = torch.ones(128, device=dev), torch.zeros(128, device=dev)
+    mm, mv = torch.zeros(128, device=dev), torch.ones(128, device=dev)
+    torch.library.opcheck(torch.ops.sph3d.elu_bn_partials, (y, partial, gamma, beta, mm, mv), test_utils=("test_schema", "test_faketensor"))
+    with pytest.raises(ValueError):
+        tf_norm._gemm_bnstats_impl(torch.randn(1000, 64, device=dev), w)      # 1000 rows: no whole tiles

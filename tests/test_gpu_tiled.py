@@ -35,7 +35,11 @@ def _cloud(kind, B, N, seed):
 def _hip_graph(dev, kind, B, N, radius, K, kernel, seed=3):
     xyz = _t(_cloud(kind, B, N, seed), dev)
     idx, cnt, dst = tf_nnquery.build_sphere_neighbor(xyz, xyz, radius, None, K)
-    filt = tf_buildkernel.spherical_kernel(xyz, xyz, idx, cnt, dst, radius, kernel)
+    _plan.set_mode("tiled")               # the binning op remembers the graph's coordinates only while a tiled mode is on
+    try:
+        filt = tf_buildkernel.spherical_kernel(xyz, xyz, idx, cnt, dst, radius, kernel)
+    finally:
+        _plan.set_mode("gather")
     return xyz, idx, cnt, filt
 
 
