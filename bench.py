@@ -122,6 +122,35 @@ def train_step(model, flat, opt, pts, label, inner):
     return loss
 
 
+def run_timed(one_step, steps, warmup, world, sync):
+    """The contract's timed region: W untimed steps, then exactly K steps bracketed by barrier + device sync on both sides;
+    -> (seconds, MAX over the ranks; last loss).  `sync` = torch.cuda.synchronize on the GPU (a no-op for the CPU/gloo test
+    that drives this same function with world 2)."""
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    for _ in range(warmup):
+        one_step()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(steps):
+        loss = one_step()
+    sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    return elapsed, loss
+
+
+def reduce_max_seconds(elapsed, world, dev):
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -132,13 +161,16 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(sample_blocks=2, timed_steps=10, warm_steps=3, budget_s=40.0):
-    """Same harness step (graph build + fwd + bwd + Adam) on the CPU oracle — kind = "port": oracle/ is the C
-    restatement of the reference's kernels, OpenMP across independent work items; GEMM / BN / ELU run in torch-CPU
-    (MKL/oneDNN) so the baseline is not handicapped.  Bounded sample: `sample_blocks` S3DIS-like 8192-point blocks per
-    step.  Protocol: a short probe picks the faster of {all hardware threads, physical cores}; then
-    `warm_steps` untimed + `timed_steps` timed steps at that thread count, MEDIAN reported; then one block at ONE thread
-    (1 untimed step was already taken; as many timed steps as fit the remaining budget, at least one)."""
+def cpu_baseline(sample_blocks=BLOCKS_PER_GPU, max_timed=5, warm_steps=1, budget_s=45.0):
+    """Same harness step (graph build + fwd + bwd + Adam) on the CPU oracle — kind = "port": oracle/ is the C restatement of
+    the reference's kernels, OpenMP across independent work items; GEMM / BN / ELU run in torch-CPU (MKL/oneDNN) so the
+    baseline is not handicapped.  Bounded sample: `sample_blocks` S3DIS-like 8192-point blocks per step — the SAME 16 blocks
+    per step the GPU processes (round 2 timed 2 blocks per step: the oracle parallelises over clouds and rows, two clouds
+    starve it — FPS is one thread per cloud — and its multi-thread figure was only 1.7x the one-thread one).  Protocol
+    (SURVEY §8d): one step at each candidate thread count {physical cores, hardware threads} picks the faster; then
+    `warm_steps` untimed and up to `max_timed` timed steps at that count inside `budget_s` seconds (at least 2), MEDIAN
+    reported; then ONE block at ONE thread; then the four level-0 oracle ops alone at one thread and at the chosen count
+    (per-op thread scaling)."""
     import oracle  # noqa: F401  (cpu_baseline leg: the oracle is the thing timed here, by design)
     from oracle import torch_ops
     hw = os.cpu_count() or 1
@@ -155,8 +187,9 @@ def cpu_baseline(sample_blocks=2, timed_steps=10, warm_steps=3, budget_s=40.0):
     with torch_ops.patched_util():
         model = s3dis_net.SPH3DS3DIS(s3dis_net.s3dis_config(NUM_POINT), device=torch.device("cpu"))
         set_threads(cands[0])
-        pred, _ = model(pts, is_training=True)
-        model.loss(pred, label, inner).backward()                       # cold step: creates the variables
+        p1, l1, i1 = pts[:1], label[:1], inner[:1]
+        pred, _ = model(p1, is_training=True)
+        model.loss(pred, l1, i1).backward()                             # cold step on one block: creates the variables
         flat = hdist.FlatGradAllReduce(model.parameters())
         opt = torch.optim.Adam([flat.flat_param], lr=1e-3, eps=1e-4)
 
@@ -168,32 +201,61 @@ def cpu_baseline(sample_blocks=2, timed_steps=10, warm_steps=3, budget_s=40.0):
         probe = {}
         for c in cands:
             set_threads(c)
-            timed(pts, label, inner)
             probe[c] = timed(pts, label, inner)
         best_c = min(probe, key=probe.get)
         set_threads(best_c)
         for _ in range(warm_steps):
             timed(pts, label, inner)
-        times = [timed(pts, label, inner) for _ in range(timed_steps)]
+        times = []
+        while len(times) < max_timed and (len(times) < 2 or (time.perf_counter() - t_start) + float(np.median(times)) < budget_s):
+            times.append(timed(pts, label, inner))
         med = float(np.median(times))
         # one thread, one block
         set_threads(1)
-        p1, l1, i1 = pts[:1], label[:1], inner[:1]
         timed(p1, l1, i1)
-        t1 = [timed(p1, l1, i1)]
-        while (time.perf_counter() - t_start) + t1[-1] < budget_s and len(t1) < 5:
-            t1.append(timed(p1, l1, i1))
+        t1 = [timed(p1, l1, i1) for _ in range(2)]
         med1 = float(np.median(t1))
+    # per-op thread scaling of the oracle's level-0 ops (4 blocks; one thread vs the chosen count)
+    scaling = {}
+    try:
+        nb = min(4, sample_blocks)
+        x4 = np.ascontiguousarray(xyz[:nb])
+        rng = np.random.RandomState(0)
+        feat = rng.randn(nb, NUM_POINT, 128).astype(np.float32)
+        filt = rng.randn(33, 128, 2).astype(np.float32)
+        gout = rng.randn(nb, NUM_POINT, 256).astype(np.float32)
+        oracle.set_num_threads(best_c)
+        idx, cnt, dst = oracle.build_sphere_neighbor(x4, x4, 0.1, None, 64)
+        bins = oracle.spherical_kernel(x4, x4, idx, cnt, dst, 0.1, [8, 2, 2])
+        ops = {"build_sphere_neighbor": lambda: oracle.build_sphere_neighbor(x4, x4, 0.1, None, 64),
+               "farthest_point_sample": lambda: oracle.farthest_point_sample(2048, x4),
+               "depthwise_conv3d": lambda: oracle.depthwise_conv3d(feat, filt, idx, cnt, bins),
+               "depthwise_conv3d_grad": lambda: oracle.depthwise_conv3d_grad(feat, filt, gout, idx, cnt, bins)}
+        for name, fn in ops.items():
+            r = []
+            for c in (1, best_c):
+                oracle.set_num_threads(c)
+                fn()
+                t0 = time.perf_counter()
+                fn()
+                r.append(time.perf_counter() - t0)
+            scaling[name] = {"s_1_thread": round(r[0], 4), "s_%d_threads" % best_c: round(r[1], 4), "speedup": round(r[0] / r[1], 1)}
+    except Exception as e:                       # a reporting aid, never a reason to lose the bench line
+        scaling = {"error": str(e)}
     return {"value": round(sample_blocks / med, 4), "unit": "blocks/s", "cores": best_c, "kind": "port",
             "cpu": _cpu_model(), "host_threads": hw,
-            "steps": {"warmup": warm_steps, "timed": timed_steps, "median_s": round(med, 4),
+            "steps": {"warmup": warm_steps, "timed": len(times), "median_s": round(med, 4),
                       "min_s": round(min(times), 4), "max_s": round(max(times), 4),
                       "probe_s_per_thread_count": {str(k): round(v, 4) for k, v in probe.items()}},
             "one_thread": {"value": round(1.0 / med1, 4), "unit": "blocks/s", "blocks_per_step": 1,
                            "timed_steps": len(t1), "median_s": round(med1, 4)},
+            "threads_vs_one_thread": round((sample_blocks / med) * med1, 2),
+            "per_op_thread_scaling_4_blocks": scaling,
+            "note": "per-cloud parallel parts of the oracle (FPS: one thread per cloud) bound the multi-thread figure: with 16 clouds "
+                    "per step at most 16 threads work during the sampling chain",
             "sample": "%d S3DIS-like 8192-pt blocks per step (full SPH3D_s3dis graph build + fwd + bwd + Adam on oracle/ "
-                      "C99+OpenMP, torch-CPU GEMM/BN): median of %d steps after %d warm-up steps at %d threads"
-                      % (sample_blocks, timed_steps, warm_steps, best_c)}
+                      "C99+OpenMP, torch-CPU GEMM/BN): median of %d steps after %d warm-up step(s) at %d threads"
+                      % (sample_blocks, len(times), warm_steps, best_c)}
 
 
 def isolated_call_seconds(name, ints, dev, reps=20):
@@ -250,6 +312,14 @@ def isolated_call_seconds(name, ints, dev, reps=20):
         return None
 
 
+def _rccl_version():
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:
+        return None
+
+
 def _self_launch(args):
     """`python bench.py --gpus N` with no launcher: re-run this script under torch.distributed.run, one rank per GPU"""
     import socket
@@ -260,6 +330,9 @@ def _self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    # every rank is a launch-issuing Python process: keep their math-library thread pools small (torch.distributed.run's own
+    # default of OMP_NUM_THREADS=1 also works; hdist.pin_rank() sets the final value from the rank's CPU slice)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, (os.cpu_count() or 8) // max(1, args.gpus)))))
     return subprocess.call(cmd, env=env)
 
 
@@ -280,6 +353,7 @@ def main():
     assert torch.cuda.device_count() >= (local_rank + 1), "rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    pinned_cpus = hdist.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     _lib.lib()
 
     batches = [make_batch(rank, dev, w) for w in range(NUM_BATCHES)]
@@ -301,10 +375,6 @@ def main():
     opt = torch.optim.Adam([flat.flat_param], lr=1e-3, eps=1e-4, fused=True)
     nparams = flat.flat_param.numel()
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
     # (launch mode: eager on three HIP streams.  A HIP-graph replay of the step was tried in round 1 and removed in round 2:
     #  capturing the three-stream step does not complete on this stack — DESIGN.md section 5)
     mode = "eager"
@@ -322,17 +392,7 @@ def main():
     for _ in range(PRIME_STEPS):
         one_step()
     torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        one_step()
-
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = one_step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, loss = run_timed(one_step, args.steps, args.warmup, world, torch.cuda.synchronize)
 
     # Per-kernel device times: the same K steps are run once more, right after the timed region (same process, same
     # data, same kernels), with every C-ABI launch bracketed by two HIP events on its launching stream.  They are
@@ -345,10 +405,7 @@ def main():
     torch.cuda.synchronize()
     events = _lib.timing_stop()
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = reduce_max_seconds(elapsed, world, dev)
 
     # ---- per-kernel device time from the HIP events recorded during the timed steps ----
     per = {}
@@ -464,7 +521,10 @@ def main():
                        "parallelism": "dp%d (one cloud shard per GPU; flat gradient all-reduced over RCCL in %d buckets, "
                                       "overlapped with backward)" % (world, len(flat.buckets)),
                        "resident_batches": NUM_BATCHES, "event_pass_steps": ev_steps,
-                       "params": nparams, "launch_mode": mode},
+                       "params": nparams, "launch_mode": mode,
+                       "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                       "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
+                       "rccl_version": _rccl_version(), "cpus_per_rank": pinned_cpus},
             "loss": round(float(loss), 5),
             "sph3d_calls_ms_per_step_summed_over_streams": round(sph3d_ms, 3),
             "families_ms_per_step": families,

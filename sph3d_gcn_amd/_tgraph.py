@@ -32,7 +32,7 @@ _orders = collections.OrderedDict()
 
 
 def set_source_order(nn_index, order):
-    _orders[_ident(nn_index)] = (order, nn_index)
+    _orders[_ident(nn_index)] = (order, nn_index, set())
     while len(_orders) > _MAX_ENTRIES:
         _orders.popitem(last=False)
 
@@ -43,7 +43,10 @@ def source_order(nn_index):
         return None
     order = hit[0]
     if order.is_cuda:
-        order.record_stream(torch.cuda.current_stream())      # built on the graph stream, read by this stream's kernels
+        cur = _lib.current_raw_stream()
+        if cur not in hit[2]:               # once per consuming stream: built on the graph stream, read by this stream's kernels
+            order.record_stream(torch.cuda.current_stream())
+            hit[2].add(cur)
     return order
 
 
@@ -54,17 +57,20 @@ def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1
     phase has already run (tf_nnquery.build_sphere_graph did it inside the neighbour search): only scan + fill remain"""
     F = int(num_bins) if bin_index is not None else 1
     key = (_ident(nn_index), _ident(nn_count), _ident(bin_index), _ident(weight), int(n_src), F, tuple(nn_index.shape))
-    cur = torch.cuda.current_stream()
+    cur_raw = _lib.current_raw_stream()
     hit = _cache.get(key)
     if hit is not None:
         _cache.move_to_end(key)
-        out, _keep, ev, built_on = hit
-        if built_on != cur.cuda_stream:          # built ahead of time on the graph stream: order this stream after it
+        out, _keep, ev, synced = hit
+        if cur_raw not in synced:                # built ahead of time on the graph stream: order this stream after it, ONCE
+            cur = torch.cuda.current_stream()
             cur.wait_event(ev)
             for t in out:
                 if t is not None:
                     t.record_stream(cur)
+            synced.add(cur_raw)
         return out
+    cur = torch.cuda.current_stream()
     B, M, K = nn_index.shape
     dev = nn_index.device
     offsets = torch.empty((B * (n_src * F + 1),), dtype=torch.int32, device=dev)
@@ -92,7 +98,7 @@ def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1
     out = (offsets, ent_key, ent_scale, active)
     ev = torch.cuda.Event()
     ev.record(cur)
-    _cache[key] = (out, (nn_index, nn_count, bin_index, weight), ev, cur.cuda_stream)
+    _cache[key] = (out, (nn_index, nn_count, bin_index, weight), ev, {cur_raw})
     while len(_cache) > _MAX_ENTRIES:
         _cache.popitem(last=False)
     return out

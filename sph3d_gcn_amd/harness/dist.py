@@ -22,6 +22,64 @@ def init_from_env(backend=None):
     return rank, world, local_rank
 
 
+def _parse_cpulist(text):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.extend(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def _gpu_numa_cpus(local_rank):
+    """host CPUs of the NUMA node the rank's GPU hangs off (sysfs), or None"""
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return None
+        return _parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read())
+    except Exception:
+        return None
+
+
+def pin_rank(local_rank, local_world, want_numa=True):
+    """Give every rank of the node its own host cores: eight Python ranks each issue ~400 launches per step, and unpinned
+    they migrate across both sockets and share cores with one another's OpenMP / autograd threads.  Rank r takes the r-th
+    slice of the CPUs of its GPU's NUMA node (sysfs) when that is known, else the r-th contiguous slice of the process's
+    affinity mask; OMP / MKL thread counts follow the slice.  -> number of CPUs the rank may run on (0 = left alone)."""
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return 0
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        mine = None
+        if want_numa and torch.cuda.is_available():
+            node = _gpu_numa_cpus(local_rank)
+            if node:
+                node = [c for c in node if c in set(allowed)]
+                # ranks sharing a node: assume GPUs are spread evenly over the nodes in index order
+                nodes = max(1, len(allowed) // max(1, len(node)))
+                per_node = max(1, (local_world + nodes - 1) // nodes)
+                k = local_rank % per_node
+                w = max(1, len(node) // per_node)
+                mine = node[k * w:(k + 1) * w]
+        if not mine:
+            w = max(1, len(allowed) // local_world)
+            mine = allowed[local_rank * w:(local_rank + 1) * w]
+        if not mine:
+            return 0
+        os.sched_setaffinity(0, mine)
+        n = max(1, min(len(mine), 8))
+        os.environ["OMP_NUM_THREADS"] = str(n)
+        os.environ["MKL_NUM_THREADS"] = str(n)
+        torch.set_num_threads(n)
+        return len(mine)
+    except Exception:
+        return 0
+
+
 def shard_range(total, rank, world):
     """Contiguous [begin, end) of `total` clouds owned by `rank` (remainder spread over the first ranks)."""
     base, rem = divmod(total, world)

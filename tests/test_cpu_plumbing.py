@@ -133,6 +133,19 @@ def test_gloo_world2_flat_grad_allreduce():
     assert "GLOO_OK" in p.stdout
 
 
+def test_gloo_world2_bench_rank_code_path():
+    """bench.py's rank path end to end with two ranks on CPU (gloo): rank init + CPU slice per rank, train_step (graph
+    build + fwd + bwd with the hooked, bucketed flat all-reduce + Adam), the contract's timed region (run_timed: barrier +
+    sync on both sides) and the MAX over ranks; the replicas must stay identical after the optimiser steps."""
+    script = os.path.join(ROOT, "tests", "_gloo_bench_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="2")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", script],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "GLOO_BENCH_OK" in p.stdout
+
+
 def test_modelnet_small_net_on_oracle_ops():
     """SPH3D_modelnet call pattern (BASELINE config #1): 1024 points, raw-xyz concatenation (odd channel
     counts 35 / 67), per-level global max-pools, global conv with K = remaining points and 17 bins, fc + dropout."""

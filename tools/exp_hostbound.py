@@ -7,7 +7,8 @@ from sph3d_gcn_amd import _lib
 from sph3d_gcn_amd.harness import dist as hdist, s3dis_net
 dev = torch.device("cuda:0")
 _lib.lib()
-batches = [bench.make_batch(0, dev, w) for w in range(2)]
+NB = int(os.environ.get("NB", "2"))
+batches = [bench.make_batch(0, dev, w) for w in range(NB)]
 torch.cuda.synchronize()
 ev = torch.cuda.Event(); ev.record()
 for bt in batches: bench._PTS_READY[bt[0].data_ptr()] = ev
@@ -20,7 +21,7 @@ flat = hdist.FlatGradAllReduce(model.parameters())
 opt = torch.optim.Adam([flat.flat_param], lr=1e-3, eps=1e-4, fused=True)
 n = [0]
 def step():
-    p, l, i = batches[n[0] % 2]; n[0] += 1
+    p, l, i = batches[n[0] % NB]; n[0] += 1
     return bench.train_step(model, flat, opt, p, l, i)
 for _ in range(25): step()
 torch.cuda.synchronize()
