@@ -457,7 +457,7 @@ def main():
         else:
             work, peak, unit, bound = ab / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
         achieved = work / avg_s
-        traffic, trace_us = None, None
+        traffic, trace_us, mfma_busy = None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
@@ -465,6 +465,7 @@ def main():
                 key = "%s%s" % (name, list(ints[:7]))
                 traffic = table.get(key, table.get("%s%s" % (name, list(ints[:6]))))
                 trace_us = table.get("trace_us", {}).get(key)
+                mfma_busy = table.get("mfma_pipe_busy", {}).get(key)      # committed PMC pass of the same call (profiles/)
             except Exception:
                 traffic = None
         roofline = {"kernel": name, "family": fname, "dims": list(ints[:7]), "bound": bound, "achieved": round(achieved, 1),
@@ -472,7 +473,7 @@ def main():
                     "alg_bytes": ab, "avg_us": round(avg_s * 1e6, 1),
                     "isolated_us": round(iso_s * 1e6, 1) if iso_s else None,
                     "isolated_frac": round(work / iso_s / peak, 4) if iso_s else None,
-                    "trace_us": trace_us, "traffic": traffic,
+                    "trace_us": trace_us, "traffic": traffic, "mfma_pipe_busy_pmc": mfma_busy,
                     "family_ms_per_step": round(fam[fname][0] / ev_steps, 3),
                     "note": "avg_us: HIP events around the C-ABI call inside the running step (three streams share the "
                             "CUs); isolated_us: the same call alone on an idle GPU; trace_us: rocprofv3 kernel trace"}

@@ -8,6 +8,7 @@ dev = torch.device('cuda:0'); _lib.lib()
 B, K, N = 16, 64, 8192
 C = int(os.environ.get("C", "128")); MODE = os.environ.get("MODE", "fwd")
 xyz = torch.from_numpy(synth.s3dis_batch(1000, B, N)[0]).to(dev)[:, :, :3].contiguous()
+_plan.set_mode("tiled" if os.environ.get("TILED") else "gather")      # before the bins: they register the geometry in tiled mode
 nidx, cnt, dst = tf_nnquery.build_sphere_neighbor(xyz, xyz, 0.1, None, K)
 filt = tf_buildkernel.spherical_kernel(xyz, xyz, nidx, cnt, dst, 0.1, [8, 2, 2])
 x = torch.randn(B, N, C, device=dev); w = torch.randn(33, C, 2, device=dev); go = torch.randn(B, N, C * 2, device=dev)
