@@ -330,14 +330,14 @@ int sph3d_elu_bn_backward(int R, int C, const float* y, const float* dout, const
 
 /* ---- fused forward of a layer tail: GEMM whose epilogue emits the batch-norm statistics' partial sums ---------------
  * (utils/sph3gcn_util.py:146-161: tf.matmul -> ELU -> tf.layers.batch_normalization; SURVEY 8f.3, first half.)
- * sph3d_pointwise_gemm_bnstats writes Y = X W (raw, the backward pass needs it) and partial[nblk][2][Cout] = per row block
+ * sph3d_pointwise_gemm_bnstats writes Y = X W (+ bias; raw, the backward pass needs it) and partial[nblk][2][Cout] = per row block
  * sum elu(y), sum elu(y)^2; nblk = sph3d_pointwise_gemm_bnstats_blocks(R, Cin, Cout), 0 when the shape does not qualify
  * (whole 128/64-row tiles, Cout a multiple of 64 — of 128 above 64 —, Cin a multiple of 16; 16-byte aligned operands):
  * then run sph3d_pointwise_gemm and sph3d_elu_bn_forward.  sph3d_elu_bn_forward_partials is sph3d_elu_bn_forward
  * (training mode) without its statistics pass over Y. */
 int sph3d_pointwise_gemm_bnstats_blocks(int R, int Cin, int Cout);
-int sph3d_pointwise_gemm_bnstats(int R, int Cin, int Cout, const float* X, const float* W, float* Y, float* partial,
-                                 sph3d_stream_t stream);
+int sph3d_pointwise_gemm_bnstats(int R, int Cin, int Cout, const float* X, const float* W, const float* bias /* [Cout] or NULL */,
+                                 float* Y, float* partial, sph3d_stream_t stream);
 int sph3d_elu_bn_forward_partials(int R, int C, int nblk, const float* partial, const float* y, const float* gamma,
                                   const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                   float* out, float* save_mean, float* save_rstd, sph3d_stream_t stream);

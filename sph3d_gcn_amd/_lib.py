@@ -65,7 +65,7 @@ SIGNATURES = {
     "sph3d_pointwise_gemm_tn": (_I, [_I] * 3 + [_P, _P, _P, _P, _S, _P]),
     "sph3d_elu_bn_workspace": (_S, [_I] * 2),
     "sph3d_pointwise_gemm_bnstats_blocks": (_I, [_I] * 3),
-    "sph3d_pointwise_gemm_bnstats": (_I, [_I] * 3 + [_P] * 5),
+    "sph3d_pointwise_gemm_bnstats": (_I, [_I] * 3 + [_P] * 6),
     "sph3d_elu_bn_forward_partials": (_I, [_I] * 3 + [_P] * 6 + [_F, _F] + [_P] * 4),
     "sph3d_elu_bn_forward": (_I, [_I, _I, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _S, _P]),
     "sph3d_elu_bn_backward": (_I, [_I, _I] + [_P] * 5 + [_I] + [_P] * 3 + [_P, _S, _P]),

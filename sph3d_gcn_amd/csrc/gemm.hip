@@ -483,8 +483,8 @@ extern "C" int sph3d_pointwise_gemm_bnstats_blocks(int R, int Cin, int Cout)
     return (R > 0 && Cin > 0 && Cout > 0) ? nn_stats_tile(R, Cout, Cin, bm, bn) : 0;
 }
 
-extern "C" int sph3d_pointwise_gemm_bnstats(int R, int Cin, int Cout, const float* X, const float* W, float* Y, float* partial,
-                                            sph3d_stream_t stream)
+extern "C" int sph3d_pointwise_gemm_bnstats(int R, int Cin, int Cout, const float* X, const float* W, const float* bias, float* Y,
+                                            float* partial, sph3d_stream_t stream)
 {
     SPH3D_REQUIRE(R > 0 && Cin > 0 && Cout > 0, "pointwise_gemm_bnstats: bad dims R=%d Cin=%d Cout=%d", R, Cin, Cout);
     int bm = 0, bn = 0;
@@ -497,13 +497,13 @@ extern "C" int sph3d_pointwise_gemm_bnstats(int R, int Cin, int Cout, const floa
     const unsigned tiles = (unsigned)((R / bm) * (Cout / bn));
     if (bm == 128 && bn == 128)
         hipLaunchKernelGGL((gemm_f32_mfma<true, false, 128, 128, BKS, false, false, true>), dim3(tiles), dim3(256), 0, st, R, Cout, Cin, X,
-                           Cin, W, Cout, Y, Cout, nullptr, 0, 0, partial);
+                           Cin, W, Cout, Y, Cout, bias, 0, 0, partial);
     else if (bm == 128)
         hipLaunchKernelGGL((gemm_f32_mfma<true, false, 128, 64, BKS, false, false, true>), dim3(tiles), dim3(256), 0, st, R, Cout, Cin, X,
-                           Cin, W, Cout, Y, Cout, nullptr, 0, 0, partial);
+                           Cin, W, Cout, Y, Cout, bias, 0, 0, partial);
     else
         hipLaunchKernelGGL((gemm_f32_mfma<true, false, 64, 64, BKS, false, false, true>), dim3(tiles), dim3(256), 0, st, R, Cout, Cin, X,
-                           Cin, W, Cout, Y, Cout, nullptr, 0, 0, partial);
+                           Cin, W, Cout, Y, Cout, bias, 0, 0, partial);
     return check_launch("sph3d_pointwise_gemm_bnstats");
 }
 

@@ -236,10 +236,10 @@ def _finish(outputs, num_out_channels, scope, activation_fn, with_bn, with_bias,
 
 
 def _fused_tail_applies(x2d, num_out_channels, activation_fn, with_bn, with_bias, is_training):
-    """GEMM + ELU + batch norm with the statistics in the GEMM's epilogue (tf_norm.gemm_elu_batch_norm): training mode, no
-    bias, shapes the statistics kernel covers"""
+    """GEMM (+ bias) + ELU + batch norm with the statistics in the GEMM's epilogue (tf_norm.gemm_elu_batch_norm): training
+    mode, shapes the statistics kernel covers"""
     training = True if is_training is None else bool(is_training)
-    return (FUSE_GEMM_BN and FUSE_ELU_BN and with_bn and not with_bias and activation_fn is elu and training and x2d.is_cuda
+    return (FUSE_GEMM_BN and FUSE_ELU_BN and with_bn and activation_fn is elu and training and x2d.is_cuda
             and tf_norm.supported(num_out_channels)
             and tf_norm.gemm_bn_blocks(x2d.shape[0], x2d.shape[1], num_out_channels) > 0)
 
@@ -248,8 +248,14 @@ def _gemm_tail(x2d, kernel, out_shape, num_out_channels, scope, activation_fn, w
     """tf.matmul -> (+ biases) -> activation -> batch norm of the three layer kinds (utils/sph3gcn_util.py:146-161,204-222,260-273)"""
     if _fused_tail_applies(x2d, num_out_channels, activation_fn, with_bn, with_bias, is_training):
         store = get_variable_store()
+        biases = store.get_variable(scope + '/biases', [num_out_channels], _constant(0.0)) if with_bias else None
         gamma, beta, moving_mean, moving_var = _bn_variables(store, scope + '/bn', num_out_channels)
-        out = tf_norm.gemm_elu_batch_norm(x2d, kernel, gamma, beta, moving_mean, moving_var)
+        out = tf_norm.gemm_elu_batch_norm(x2d, kernel, gamma, beta, moving_mean, moving_var, bias=biases)
+        return out.reshape(out_shape)
+    if (FUSE_GEMM_BN and with_bias and not with_bn and x2d.is_cuda and (activation_fn is elu or activation_fn is None)):
+        # biases (and ELU) in the GEMM's epilogue: the tail of a layer without batch norm (utils/sph3gcn_util.py:152-155)
+        biases = get_variable_store().get_variable(scope + '/biases', [num_out_channels], _constant(0.0))
+        out = tf_gemm.matmul_bias_act(x2d, kernel, biases, elu=activation_fn is elu)
         return out.reshape(out_shape)
     outputs = tf_gemm.matmul(x2d, kernel).reshape(out_shape)
     return _finish(outputs, num_out_channels, scope, activation_fn, with_bn, with_bias, reuse, is_training)
@@ -324,8 +330,8 @@ def fully_connected(inputs,
     num_in_channels = inputs.shape[-1]
     kernel = _variable_with_weight_decay(scope + '/weights', shape=[num_in_channels, num_out_channels],
                                          use_xavier=use_xavier, stddev=stddev, with_decay=weight_decay)
-    outputs = tf_gemm.matmul(inputs, kernel)
-    return _finish(outputs, num_out_channels, scope, activation_fn, with_bn, with_bias, reuse, is_training)
+    return _gemm_tail(inputs, kernel, (inputs.shape[0], num_out_channels), num_out_channels, scope, activation_fn, with_bn,
+                      with_bias, reuse, is_training)
 
 
 def pool3d(inputs, nn_index, nn_count, scope, method):

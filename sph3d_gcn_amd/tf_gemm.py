@@ -87,3 +87,49 @@ class _PointwiseGemmFn(torch.autograd.Function):      # eager fast path (see tf_
 
 def matmul(x, w):
     return _PointwiseGemmFn.apply(x, w)
+
+
+# ---- GEMM with the bias / ELU epilogue of the library (layers with biases and no batch norm) --------------------------
+def _gemm_bias_act_impl(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, act: int) -> torch.Tensor:
+    """elu?(x[R,Cin] @ w[Cin,Cout] + bias[Cout]); act = 0 (none) | 1 (ELU): bias and activation run in the GEMM's epilogue"""
+    _lib.require_device(x, w, bias)
+    x, w, bias = _lib.f32(x), _lib.f32(w), _lib.f32(bias)
+    R, Cin = x.shape
+    Cout = w.shape[1]
+    y = torch.empty((R, Cout), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().sph3d_pointwise_gemm(R, Cin, Cout, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), int(act), 0,
+                                               _lib.ptr(y), _lib.stream_ptr()))
+    return y
+
+
+_gemm_bias_act = torch.library.custom_op("sph3d::pointwise_gemm_bias_act", mutates_args=())(_gemm_bias_act_impl)
+
+
+@_gemm_bias_act.register_fake
+def _(x, w, bias, act):
+    return x.new_empty((x.shape[0], w.shape[1]))
+
+
+class _GemmBiasActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, act):
+        out = _gemm_bias_act_impl(x, w, bias, act)
+        ctx.save_for_backward(x, w, out)
+        ctx.act = act
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, out = ctx.saved_tensors
+        # ELU'(z) from the output: 1 for z > 0, elu(z) + 1 = exp(z) otherwise
+        g = dout * torch.where(out > 0, torch.ones_like(out), out + 1.0) if ctx.act == 1 else dout
+        g = g.contiguous()
+        dx = _pointwise_gemm_impl(g, w, True) if ctx.needs_input_grad[0] else None
+        dw = _pointwise_gemm_tn_impl(x, g) if ctx.needs_input_grad[1] else None
+        db = g.sum(0) if ctx.needs_input_grad[2] else None
+        return dx, dw, db, None
+
+
+def matmul_bias_act(x, w, bias, elu=False):
+    """elu?(x @ w + bias) with the bias and the activation in the GEMM's epilogue"""
+    return _GemmBiasActFn.apply(x, w, bias, 1 if elu else 0)

@@ -5,7 +5,7 @@ epsilon=1e-3); stock TF ops in the reference, SURVEY §8f item 3 here).
 ``elu_batch_norm(y, gamma, beta, moving_mean, moving_var, training)`` == batch_norm(elu(y)) over all but the last axis,
 as ONE custom op (``sph3d::elu_bn``) whose backward needs only y.
 """
-from typing import Tuple
+from typing import Optional, Tuple
 
 import torch
 
@@ -98,10 +98,12 @@ def gemm_bn_blocks(R, Cin, Cout):
     return int(_lib.lib().sph3d_pointwise_gemm_bnstats_blocks(int(R), int(Cin), int(Cout)))
 
 
-def _gemm_bnstats_impl(x: torch.Tensor, w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """y[R,Cout] = x @ w and partial[nblk, 2, Cout] = per row block (sum elu(y), sum elu(y)^2)"""
+def _gemm_bnstats_impl(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """y[R,Cout] = x @ w (+ bias) and partial[nblk, 2, Cout] = per row block (sum elu(y), sum elu(y)^2)"""
     _lib.require_device(x, w)
     x, w = _lib.f32(x), _lib.f32(w)
+    if bias is not None:
+        bias = _lib.f32(bias)
     R, Cin = x.shape
     Cout = w.shape[1]
     nblk = gemm_bn_blocks(R, Cin, Cout)
@@ -109,8 +111,8 @@ def _gemm_bnstats_impl(x: torch.Tensor, w: torch.Tensor) -> Tuple[torch.Tensor, 
         raise ValueError("pointwise_gemm_bnstats: shape (%d, %d -> %d) is not covered (whole tiles needed)" % (R, Cin, Cout))
     y = torch.empty((R, Cout), dtype=torch.float32, device=x.device)
     partial = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().sph3d_pointwise_gemm_bnstats(R, Cin, Cout, _lib.ptr(x), _lib.ptr(w), _lib.ptr(y), _lib.ptr(partial),
-                                                        _lib.stream_ptr()))
+    _lib.check(_lib.lib().sph3d_pointwise_gemm_bnstats(R, Cin, Cout, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y),
+                                                        _lib.ptr(partial), _lib.stream_ptr()))
     return y, partial
 
 
@@ -136,7 +138,7 @@ _elu_bn_partials = torch.library.custom_op("sph3d::elu_bn_partials", mutates_arg
 
 
 @_gemm_bnstats.register_fake
-def _(x, w):
+def _(x, w, bias=None):
     nblk = gemm_bn_blocks(x.shape[0], x.shape[1], w.shape[1])
     return x.new_empty((x.shape[0], w.shape[1])), x.new_empty((nblk, 2, w.shape[1]))
 
@@ -151,10 +153,11 @@ class _GemmEluBnFn(torch.autograd.Function):
     product y; the backward is elu_bn's followed by the GEMM's two gradient products."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, moving_mean, moving_var):
-        y, partial = _gemm_bnstats_impl(x, w)
+    def forward(ctx, x, w, bias, gamma, beta, moving_mean, moving_var):
+        y, partial = _gemm_bnstats_impl(x, w, bias)
         out, save_mean, save_rstd = _elu_bn_partials_impl(y, partial, gamma, beta, moving_mean, moving_var)
         ctx.save_for_backward(x, w, y, gamma, save_mean, save_rstd)
+        ctx.has_bias = bias is not None
         return out
 
     @staticmethod
@@ -164,9 +167,10 @@ class _GemmEluBnFn(torch.autograd.Function):
         dy, dgamma, dbeta = _bwd_impl(y, dout, gamma, save_mean, save_rstd, True)
         dx = tf_gemm._pointwise_gemm_impl(dy, w, True) if ctx.needs_input_grad[0] else None
         dw = tf_gemm._pointwise_gemm_tn_impl(x, dy) if ctx.needs_input_grad[1] else None
-        return dx, dw, dgamma, dbeta, None, None
+        db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, dgamma, dbeta, None, None
 
 
-def gemm_elu_batch_norm(x, w, gamma, beta, moving_mean, moving_var):
-    """x[R,Cin] @ w[Cin,Cout] -> ELU -> batch norm (training statistics), one fused tail"""
-    return _GemmEluBnFn.apply(x, w, gamma, beta, moving_mean, moving_var)
+def gemm_elu_batch_norm(x, w, gamma, beta, moving_mean, moving_var, bias=None):
+    """x[R,Cin] @ w[Cin,Cout] (+ bias) -> ELU -> batch norm (training statistics), one fused tail"""
+    return _GemmEluBnFn.apply(x, w, bias, gamma, beta, moving_mean, moving_var)

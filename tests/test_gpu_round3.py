@@ -267,8 +267,10 @@ def test_gemm_bnstats_ops_registered(dev):
     from sph3d_gcn_amd import tf_norm
     x = torch.randn(1024, 64, device=dev)
     w = torch.randn(64, 128, device=dev)
-    torch.library.opcheck(torch.ops.sph3d.pointwise_gemm_bnstats, (x, w), test_utils=("test_schema", "test_faketensor"))
-    y, partial = torch.ops.sph3d.pointwise_gemm_bnstats(x, w)
+    torch.library.opcheck(torch.ops.sph3d.pointwise_gemm_bnstats, (x, w, None), test_utils=("test_schema", "test_faketensor"))
+    torch.library.opcheck(torch.ops.sph3d.pointwise_gemm_bias_act, (x, w, torch.randn(128, device=dev), 1),
+                          test_utils=("test_schema", "test_faketensor"))
+    y, partial = torch.ops.sph3d.pointwise_gemm_bnstats(x, w, None)
     z = torch.nn.functional.elu(y.double())
     np.testing.assert_allclose(_n(partial[:, 0].double().sum(0)), _n(z.sum(0)), rtol=1e-5, atol=1e-3)
     np.testing.assert_allclose(_n(partial[:, 1].double().sum(0)), _n((z * z).sum(0)), rtol=1e-5, atol=1e-3)
@@ -278,3 +280,63 @@ def test_gemm_bnstats_ops_registered(dev):
     torch.library.opcheck(torch.ops.sph3d.elu_bn_partials, (y, partial, gamma, beta, mm, mv), test_utils=("test_schema", "test_faketensor"))
     with pytest.raises(ValueError):
         tf_norm._gemm_bnstats_impl(torch.randn(1000, 64, device=dev), w)      # 1000 rows: no whole tiles
+
+
+@pytest.mark.parametrize("R,Cin,Cout", [(4096, 64, 128), (1000, 35, 40), (2048, 256, 13)])
+@pytest.mark.parametrize("act", [True, False])
+def test_gemm_bias_elu_epilogue_forward_backward(dev, R, Cin, Cout, act):
+    """utils/sph3gcn_util.py:152-155 (biases, then the activation) inside the GEMM's epilogue, with its gradients, vs float64"""
+    from sph3d_gcn_amd import tf_gemm
+    g = torch.Generator().manual_seed(R + Cout)
+    x = torch.randn(R, Cin, generator=g).to(dev)
+    w = (torch.randn(Cin, Cout, generator=g) / Cin ** 0.5).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    dout = torch.randn(R, Cout, generator=g).to(dev)
+    xs, ws, bs = (t.clone().requires_grad_(True) for t in (x, w, b))
+    out = tf_gemm.matmul_bias_act(xs, ws, bs, elu=act)
+    out.backward(dout)
+    xd, wd, bd = (t.double().clone().requires_grad_(True) for t in (x, w, b))
+    ref = xd @ wd + bd
+    ref = torch.nn.functional.elu(ref) if act else ref
+    ref.backward(dout.double())
+    for nm, a, r in (("out", out, ref), ("dx", xs.grad, xd.grad), ("dw", ws.grad, wd.grad), ("db", bs.grad, bd.grad)):
+        scale = max(1.0, float(r.abs().max()))
+        np.testing.assert_allclose(_n(a) / scale, _n(r.float()) / scale, rtol=2e-5, atol=2e-5, err_msg=nm)
+
+
+@pytest.mark.parametrize("with_bn", [True, False])
+def test_layers_with_biases_fused_tail_equals_unfused(dev, with_bn):
+    """pointwise_conv3d / separable_conv3d / fully_connected with with_bias=True: the fused tails (bias in the GEMM epilogue,
+    statistics from the epilogue) == the reference's op-by-op tail (matmul, + biases, ELU, batch norm)"""
+    xyz = _t(synth.s3dis_batch(3, 2, 1024, extent=(1.0, 1.0, 1.5))[0], dev)
+    idx, cnt, dst, filt = s3g_util.build_intra_graph(xyz, 0.15, 32, [8, 2, 2])
+    feat = torch.randn(2, 1024, 32, device=dev)
+
+    def run(fused):
+        s3g_util.FUSE_GEMM_BN = fused
+        store = s3g_util.VariableStore(device=dev, seed=11)
+        with s3g_util.variable_store(store):
+            a = s3g_util.pointwise_conv3d(feat, 64, 'p1', with_bn=with_bn, with_bias=True, is_training=True)
+            b = s3g_util.separable_conv3d(a, 128, 33, 2, 'c1', idx, cnt, filt, with_bn=with_bn, with_bias=True, is_training=True)
+            c = s3g_util.fully_connected(b.reshape(-1, 128), 64, 'f1', with_bn=with_bn, with_bias=True, is_training=True)
+        with torch.no_grad():
+            for n, p in store.params.items():
+                if 'biases' in n:
+                    p.add_(0.3)                      # non-zero biases (they are created as zeros)
+        with s3g_util.variable_store(store):
+            a = s3g_util.pointwise_conv3d(feat, 64, 'p1', with_bn=with_bn, with_bias=True, is_training=True)
+            b = s3g_util.separable_conv3d(a, 128, 33, 2, 'c1', idx, cnt, filt, with_bn=with_bn, with_bias=True, is_training=True)
+            c = s3g_util.fully_connected(b.reshape(-1, 128), 64, 'f1', with_bn=with_bn, with_bias=True, is_training=True)
+        c.square().mean().backward()
+        return c.detach(), {n: p.grad.detach().clone() for n, p in store.params.items()}
+
+    try:
+        out_f, g_f = run(True)
+        out_u, g_u = run(False)
+    finally:
+        s3g_util.FUSE_GEMM_BN = True
+    assert g_f.keys() == g_u.keys() and any('biases' in n for n in g_f)
+    np.testing.assert_allclose(_n(out_f), _n(out_u), rtol=2e-5, atol=2e-5)
+    for n in g_f:
+        scale = max(1e-3, float(g_u[n].abs().max()))
+        np.testing.assert_allclose(_n(g_f[n]) / scale, _n(g_u[n]) / scale, rtol=2e-4, atol=2e-4, err_msg=n)
