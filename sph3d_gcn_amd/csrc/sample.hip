@@ -197,6 +197,130 @@ __global__ __launch_bounds__(1024) void fps_big_kernel(int b, int n, int m, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Large clouds (n > 24 576 points: BASELINE config 5, one 65 536-point block per GPU), round 3.  fps_big_kernel above keeps
+// one workgroup per cloud and re-reads the cloud's coordinates and running distances from L2 every round: 15 us per round,
+// 245 ms for 65 536 -> 16 384.  Here G = ceil(n / 4096) workgroups SHARE a cloud: workgroup g owns points [4096 g, 4096 g +
+// 4096) in registers (thread t: k = 4096 g + t + 1024 p, p < 4), finds its candidate like fps_reg_kernel, and the G
+// candidates meet through 8-byte data-tagged granules in global memory:
+//     [63:32] order-preserving bits of the candidate's min-distance   [31:22] 1023 - t   [21:14] 255 - (k >> 10)   [13:0] round
+// one relaxed agent-scope store per workgroup and round, polled by lane g' < G of wave 0 with relaxed agent-scope loads until
+// every tag equals the round (MI355X_MICROARCH.md: a naturally aligned 8-byte granule written by ONE store needs no further
+// ordering; slots alternate with the round's parity, so a workgroup one round ahead never overwrites what a slower one still
+// reads).  The maximum of the upper 50 bits is the reference's winner: larger distance, then lower thread id t = k mod 1024,
+// then lower k (tf_sample_gpu.cu:49,56-66: strict > inside a thread, left entry wins in the tree).  The winner's coordinates
+// are read from the (read-only) cloud.  Every spin is bounded: a workgroup that waits 2^22 polls sets the error word and the
+// kernel ends (the launcher's workgroups are all resident by construction: B * G <= 128 workgroups of 1024 threads).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kCoopP = 4;                  // points per thread
+constexpr int kCoopPts = kRefBlock * kCoopP;
+
+__global__ __launch_bounds__(1024) void fps_coop_kernel(int n, int m, int G, const float* __restrict__ dataset,
+                                                        unsigned long long* __restrict__ slots, int* __restrict__ err,
+                                                        int* __restrict__ idxs)
+{
+    __shared__ FpsSlot16 lslots[2][16];
+    __shared__ int lslot_tp[2][16];          // winner thread's t | p << 16
+    __shared__ int win_k[2];
+    const int t = (int)threadIdx.x;
+    const int lane = t & 63;
+    const int wave = uniform(t >> 6);
+    const int i = (int)blockIdx.x / G, g = (int)blockIdx.x % G;
+    const float* pts = dataset + (size_t)i * n * 3;
+    unsigned long long* myslots = slots + (size_t)i * 2 * G;
+    float px[kCoopP], py[kCoopP], pz[kCoopP], td[kCoopP];
+#pragma unroll
+    for (int p = 0; p < kCoopP; p++) {
+        const int k = g * kCoopPts + t + p * kRefBlock;
+        const bool ok = k < n;
+        px[p] = ok ? pts[k * 3] : 0.f;
+        py[p] = ok ? pts[k * 3 + 1] : 0.f;
+        pz[p] = ok ? pts[k * 3 + 2] : 0.f;
+        td[p] = ok ? 1e38f : -1.f;
+    }
+    float x1 = pts[0], y1 = pts[1], z1 = pts[2];
+    if (g == 0 && t == 0) idxs[(size_t)i * m] = 0;
+    if (t < 32) lslots[t >> 4][t & 15].vbits = 0u;
+    __syncthreads();
+
+    for (int j = 1; j < m; j++) {
+        float best = -1.f;
+        int bestp = 0;
+#pragma unroll
+        for (int p = 0; p < kCoopP; p++) {
+            const float dx = px[p] - x1, dy = py[p] - y1, dz = pz[p] - z1;
+            const float d = (dx * dx + dy * dy) + dz * dz;               // tf_sample_gpu.cu:45
+            const float d2 = d < td[p] ? d : td[p];
+            td[p] = d2;
+            if (d2 > best) { best = d2; bestp = p; }                     // :49 strict >
+        }
+        const unsigned vb = order_bits(best);
+        const unsigned wmax = wave_max_u32(vb);
+        const int wl = (int)__builtin_ctzll(__ballot(vb == wmax));
+        const int buf = j & 1;
+        if (lane == wl) {
+            lslots[buf][wave].vbits = vb;
+            lslot_tp[buf][wave] = t | (bestp << 16);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // this workgroup's candidate (lowest wave wins ties: lower t) ...
+            const unsigned sv = lslots[buf][lane & 15].vbits;
+            const unsigned gmax = wave_max_u32(sv);
+            const int gw = (int)__builtin_ctzll(__ballot(sv == gmax));           // < 16
+            const int tp = lslot_tp[buf][gw];
+            const int wt = tp & 0xffff, wp = tp >> 16;
+            const int q = g * kCoopP + wp;                                       // k >> 10 of the candidate (absent points: vb of -1)
+            const unsigned long long gran = ((unsigned long long)gmax << 32) | ((unsigned long long)(1023 - wt) << 22) |
+                                            ((unsigned long long)(255 - q) << 14) | (unsigned long long)(j & 0x3fff);
+            if (lane == 0) __hip_atomic_store(&myslots[buf * G + g], gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ... meets the other workgroups' candidates
+            const int gl = lane < G ? lane : 0;
+            unsigned long long v = 0ull;
+            int spins = 0;
+            for (;;) {
+                v = __hip_atomic_load(&myslots[buf * G + gl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ok = (int)(v & 0x3fffull) == (j & 0x3fff);
+                if (__ballot(ok) == ~0ull) break;
+                if (++spins > (1 << 22) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v = ~0ull;                                                   // poison: the round loop ends below
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            unsigned long long key = v >> 14;
+            if (v == ~0ull) key = ~0ull;
+#pragma unroll
+            for (int s2 = 1; s2 < 64; s2 <<= 1) {
+                const unsigned long long o = shfl_xor_u64(key, s2);
+                key = o > key ? o : key;
+            }
+            if (lane == 0) {
+                int k = -1;
+                if (key != ~0ull) {
+                    const int kt = 1023 - (int)((key >> 8) & 0x3ffull);
+                    const int kq = 255 - (int)(key & 0xffull);
+                    const float bv = __uint_as_float(0);
+                    (void)bv;
+                    k = kq * kRefBlock + kt;
+                    // best < 0 everywhere (no point left: cannot happen for m <= n) -> index 0 like the reference's idle threads
+                    if ((unsigned)(key >> 18) == order_bits(-1.f)) k = 0;
+                    if (k >= n) k = 0;
+                }
+                win_k[buf] = k;
+                if (g == 0 && k >= 0) idxs[(size_t)i * m + j] = k;
+            }
+        }
+        __syncthreads();
+        const int k = win_k[buf];
+        if (k < 0) break;                                                        // time-out: give up (err is set)
+        x1 = pts[(size_t)k * 3];
+        y1 = pts[(size_t)k * 3 + 1];
+        z1 = pts[(size_t)k * 3 + 2];
+    }
+}
+
 constexpr int kFpsMaxRegPoints = 24;   // points per thread held in registers
 constexpr int kFpsBigGrid = 64;
 
@@ -204,10 +328,19 @@ constexpr int kFpsBigGrid = 64;
 
 using namespace sph3d;
 
+// co-operative kernel: G workgroups per cloud, all B * G resident at once (<= 128 of the 256 CUs)
+static int coop_groups(int b, int n)
+{
+    const int G = (n + kCoopPts - 1) / kCoopPts;
+    return (G <= 64 && (long long)b * G <= 128) ? G : 0;
+}
+
 extern "C" size_t sph3d_farthest_point_sample_workspace(int b, int n, int m)
 {
     (void)m;
     if (n <= kRefBlock * kFpsMaxRegPoints) return 0;
+    const int G = coop_groups(b, n);
+    if (G) return 256 + sizeof(unsigned long long) * (size_t)b * 2 * G;          // error word + granule slots
     const int g = b < kFpsBigGrid ? b : kFpsBigGrid;
     return sizeof(float) * (size_t)g * n;
 }
@@ -237,8 +370,17 @@ extern "C" int sph3d_farthest_point_sample(int b, int n, int m, const float* inp
             set_error("FarthestPointSample: workspace %zu B < required %zu B", workspace_bytes, need);
             return SPH3D_EWORKSPACE;
         }
-        const int g = b < kFpsBigGrid ? b : kFpsBigGrid;
-        hipLaunchKernelGGL(fps_big_kernel, dim3(g), dim3(kRefBlock), 0, st, b, n, m, inp, (float*)workspace, out);
+        const int G = coop_groups(b, n);
+        if (G) {
+            int rc = check_hip(hipMemsetAsync(workspace, 0, need, st), "FarthestPointSample: memset");
+            if (rc) return rc;
+            int* err = (int*)workspace;
+            unsigned long long* slots = (unsigned long long*)((char*)workspace + 256);
+            hipLaunchKernelGGL(fps_coop_kernel, dim3(b * G), dim3(kRefBlock), 0, st, n, m, G, inp, slots, err, out);
+        } else {
+            const int g = b < kFpsBigGrid ? b : kFpsBigGrid;
+            hipLaunchKernelGGL(fps_big_kernel, dim3(g), dim3(kRefBlock), 0, st, b, n, m, inp, (float*)workspace, out);
+        }
     }
 #undef SPH3D_FPS
     return check_launch("sph3d_farthest_point_sample");

@@ -340,3 +340,23 @@ def test_layers_with_biases_fused_tail_equals_unfused(dev, with_bn):
     for n in g_f:
         scale = max(1e-3, float(g_u[n].abs().max()))
         np.testing.assert_allclose(_n(g_f[n]) / scale, _n(g_u[n]) / scale, rtol=2e-4, atol=2e-4, err_msg=n)
+
+
+@pytest.mark.parametrize("B,n,m", [(1, 65536, 16384), (2, 30000, 2500), (1, 24577, 300), (3, 40000, 1000)])
+def test_fps_large_clouds_cooperative_kernel_bitexact(dev, B, n, m):
+    """clouds of more than 24 576 points: several workgroups share a cloud and exchange their candidates through tagged
+    granules (csrc/sample.hip: fps_coop_kernel).  Whole index sequences == oracle (tf_sample_gpu.cu:7-73 semantics), incl. a
+    cloud size that leaves the last workgroup partly empty and exact ties (duplicated points)."""
+    rng = np.random.RandomState(n + m)
+    xyz = (rng.rand(B, n, 3) * np.array([6.0, 6.0, 3.0])).astype(np.float32)
+    xyz[:, 5000:5200] = xyz[:, 100:300]                      # exact duplicates: equal distances -> the tie-break decides
+    xyz[:, n - 50:] = xyz[:, 1024:1074]
+    xt = _t(xyz, dev)
+    tf_sample.farthest_point_sample(m, xt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = _n(tf_sample.farthest_point_sample(m, xt))
+    dt = time.perf_counter() - t0
+    want = oracle.farthest_point_sample(m, xyz)
+    np.testing.assert_array_equal(got, want)
+    print("\nFPS %d x %d -> %d: %.1f ms" % (B, n, m, dt * 1e3))
