@@ -342,6 +342,20 @@ int sph3d_elu_bn_forward_partials(int R, int C, int nblk, const float* partial, 
                                   const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                   float* out, float* save_mean, float* save_rstd, sph3d_stream_t stream);
 
+/* ---- fused separable convolution for inference ---------------------------------------------------------
+ * The whole layer of utils/sph3gcn_util.py:134-161 with is_training=False in one kernel: DepthwiseConv3d
+ * (tf_conv3d.cpp:34-107 / tf_conv3d_gpu.cu:7-29) -> matmul with pointwise_weights[C*r][Cout] -> + bias[Cout] (NULL: none)
+ * -> act (0 none | 1 ELU) -> y*scale[Cout] + shift[Cout] (NULL: identity; batch norm with the moving statistics is
+ * scale = gamma / sqrt(moving_var + eps), shift = beta - moving_mean*scale).  output [B, M, Cout]; the [B, M, C*r] depthwise
+ * tensor is never written.  Shapes: r in {1, 2}, C <= 128 a multiple of 4, Cout <= 128 a multiple of 16, F <= 254;
+ * sph3d_separable_conv3d_fused_supported() -> 1 | 0, and the call returns SPH3D_EUNSUPPORTED outside them (run
+ * sph3d_depthwise_conv3d_forward + sph3d_pointwise_gemm then). */
+int sph3d_separable_conv3d_fused_supported(int N, int F, int C, int r, int K, int Cout);
+int sph3d_separable_conv3d_fused(int B, int N, int M, int F, int C, int r, int K, int Cout, int act,
+                                 const int* nn_index, const int* nn_count, const int* bin_index, const float* input,
+                                 const float* depthwise_filter, const float* pointwise_weights, const float* bias,
+                                 const float* scale, const float* shift, float* output, sph3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,8 @@ SIGNATURES = {
     "sph3d_elu_bn_workspace": (_S, [_I] * 2),
     "sph3d_pointwise_gemm_bnstats_blocks": (_I, [_I] * 3),
     "sph3d_pointwise_gemm_bnstats": (_I, [_I] * 3 + [_P] * 6),
+    "sph3d_separable_conv3d_fused_supported": (_I, [_I] * 6),
+    "sph3d_separable_conv3d_fused": (_I, [_I] * 9 + [_P] * 11),
     "sph3d_elu_bn_forward_partials": (_I, [_I] * 3 + [_P] * 6 + [_F, _F] + [_P] * 4),
     "sph3d_elu_bn_forward": (_I, [_I, _I, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _S, _P]),
     "sph3d_elu_bn_backward": (_I, [_I, _I] + [_P] * 5 + [_I] + [_P] * 3 + [_P, _S, _P]),
@@ -126,7 +128,7 @@ def timing_stop():
     return out
 
 
-_NO_TIME = ("sph3d_abi_version", "sph3d_last_error", "sph3d_build_info", "workspace", "_blocks")
+_NO_TIME = ("sph3d_abi_version", "sph3d_last_error", "sph3d_build_info", "workspace", "_blocks", "_supported")
 
 
 class _Proxy:

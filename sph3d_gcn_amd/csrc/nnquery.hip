@@ -26,6 +26,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kWavesPerWG = 16;
 constexpr int kMaxChunk = 12288;   // points per LDS chunk (3 * 12288 * 4 B = 144 KB)
+constexpr int kThrTable = 64;      // positions of the radius sequence with a precomputed threshold
 
 // the reference's predicate on the euclidean distance s (tf_nnquery_gpu.cu:49)
 __device__ __forceinline__ bool in_range(float s, float r)
@@ -55,16 +56,48 @@ __device__ float range_threshold(float r)
     return __uint_as_float(hi);
 }
 
-// stage `cn` points starting at point c0 of one cloud into SoA LDS arrays
-__device__ __forceinline__ void stage_cloud(const float* __restrict__ dbi, int c0, int cn, int chunkN, float* lds)
+// LDS image of a cloud chunk: blocks of 128 points (one trip of the scan = two strips of 64), each block
+// x[strip 0][64] x[strip 1][64] y[0][64] y[1][64] z[0][64] z[1][64] (384 floats).  A lane's operands for the two strips of
+// a trip are then sp[0], sp[64] (x), sp[128], sp[192] (y), sp[256], sp[320] (z) from ONE address register: three
+// ds_read2st64_b32, each filling the register PAIR the packed subtract wants.  The chunk is padded to whole trips with a
+// sentinel coordinate whose squared distance to any finite query overflows to +inf: d2 < T is false for every threshold,
+// so the scan needs no bounds masks.
+constexpr float kPadCoord = 3.0e38f;
+__device__ __forceinline__ int strip_off(int k, int comp) { return (k >> 7) * 384 + comp * 128 + (k & 127); }
+
+// stage `cn` points starting at point c0 of one cloud
+__device__ __forceinline__ void stage_cloud(const float* __restrict__ dbi, int c0, int cn, float* lds)
 {
     const float* src = dbi + (size_t)c0 * 3;
     for (int e = threadIdx.x; e < cn * 3; e += blockDim.x) {
         const float v = src[e];
         const int pnt = e / 3;
         const int comp = e - pnt * 3;
-        lds[comp * chunkN + pnt] = v;
+        lds[strip_off(pnt, comp)] = v;
     }
+    const int cpad = (cn + 127) & ~127;
+    for (int e = cn * 3 + (int)threadIdx.x; e < cpad * 3; e += blockDim.x) {
+        const int pnt = e / 3;
+        const int comp = e - pnt * 3;
+        lds[strip_off(pnt, comp)] = kPadCoord;
+    }
+}
+
+// old with lane `lane` replaced by `val` (both wave-uniform): v_writelane_b32 through the compiler's own intrinsic (it
+// routes the lane select through M0: one SGPR operand per VALU instruction on gfx9)
+extern "C" __device__ int sph3d_writelane_i32(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ int write_lane(int old, int val, int lane) { return sph3d_writelane_i32(val, lane, old); }
+
+// exclusive prefix sum of v over the lanes of a wave (all lanes active)
+__device__ __forceinline__ int wave_excl_scan(int v)
+{
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(incl, o);
+        if (lane_id() >= o) incl += u;
+    }
+    return incl - v;
 }
 
 // DEFER: the hits of a query are collected as bare indices in a per-chain LDS list during the scan, and the outputs of
@@ -92,10 +125,24 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
     int* __restrict__ nnIndex, int* __restrict__ nnCount, float* __restrict__ nnDist)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const float* lx = lds;
-    const float* ly = lds + chunkN;
-    const float* lz = lds + 2 * chunkN;
-    int* lhits = reinterpret_cast<int*>(lds + 3 * chunkN);      // [wave][CPW][K] when DEFER
+    int* lhits = reinterpret_cast<int*>(lds + 3 * ((chunkN + 127) & ~127));      // [wave][CPW][K] when DEFER
+    // Every chain's radius walks the SAME sequence r_0 = radius0, r_{k+1} = float(double(r_k) + 0.05) (tf_nnquery_gpu.cu:59);
+    // only the position k differs.  The exact thresholds T(r_k) of the first kThrTable positions are found once per workgroup
+    // (four 6-round searches per wave) instead of once per chain and pass: the search was a third of the kernel's
+    // instructions at S3DIS level 0 (32 queries per wave, ~400 instructions each).
+    float* lthr = reinterpret_cast<float*>(lhits + (DEFER ? kWavesPerWG * CPW * K : 0));   // [kThrTable]
+    {
+        const int w = (int)threadIdx.x >> 6;
+        float rk = radius0;
+        for (int k = 0; k < kThrTable; k++) {
+            if ((k & (kWavesPerWG - 1)) == w) {
+                const float T = range_threshold(rk);
+                if (lane_id() == 0) lthr[k] = T;
+            }
+            rk = (float)((double)rk + 0.05);
+        }
+        __syncthreads();
+    }
 
     const int nt = M < kRefBlock ? M : kRefBlock;
     const int bb = (int)blockIdx.x / groups;     // reference block id  (= cloud index mod 32)
@@ -105,11 +152,17 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
 
     int t[CPW];        // reference thread id of each chain
     float r[CPW];      // the chain's running radius (carried across queries AND clouds)
+    int kpos[CPW];     // its position in the radius sequence: r[c] = r_kpos
 #pragma unroll
     for (int c = 0; c < CPW; c++) {
         t[c] = (g * kWavesPerWG + wave) * CPW + c;
         r[c] = radius0;
+        kpos[c] = 0;
     }
+
+    auto threshold_of = [&](int c) -> float {
+        return kpos[c] < kThrTable ? uniformf(lthr[kpos[c]]) : range_threshold(r[c]);
+    };
 
     for (int i = bb; i < B; i += kRefGrid) {
         const float* dbi = database + (size_t)i * N * 3;
@@ -126,20 +179,48 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
             passes[c] = 0;
             qx[c] = qy[c] = qz[c] = 0.0f;
             thr[c] = 0.0f;
-            if (fixed) r[c] = radius0;          // fixed-radius mode: nothing is carried from cloud to cloud
+            if (fixed) { r[c] = radius0; kpos[c] = 0; }         // fixed-radius mode: nothing is carried from cloud to cloud
             if (has[c]) {
                 qx[c] = qi[j[c] * 3];
                 qy[c] = qi[j[c] * 3 + 1];
                 qz[c] = qi[j[c] * 3 + 2];
-                thr[c] = range_threshold(r[c]);
+                thr[c] = threshold_of(c);
             }
         }
 
         if (!MULTI) {
             __syncthreads();   // previous cloud's scans are finished
-            stage_cloud(dbi, 0, N, chunkN, lds);
+            stage_cloud(dbi, 0, N, lds);
             __syncthreads();
         }
+
+        // DEFER: hit-mask records of the current window of trips and the expansion into the chain's LDS slot list
+        int rec[CPW][4];
+        int written[CPW];       // hits of the chain's current pass that are already in its slot list (wave-uniform)
+#pragma unroll
+        for (int c = 0; c < CPW; c++) {
+            rec[c][0] = rec[c][1] = rec[c][2] = rec[c][3] = 0;
+            written[c] = 0;
+        }
+        int wtrip = 0, wbase = 0;       // trips recorded in the window; index of the window's first point
+        auto flush_hits = [&](int c) {
+            if (s[c] == written[c]) return;            // nothing recorded (wave-uniform)
+            unsigned long long m0 = (unsigned long long)(unsigned)rec[c][0] | ((unsigned long long)(unsigned)rec[c][1] << 32);
+            unsigned long long m1 = (unsigned long long)(unsigned)rec[c][2] | ((unsigned long long)(unsigned)rec[c][3] << 32);
+            int pos = written[c] + wave_excl_scan(__popcll(m0) + __popcll(m1));
+            int* h = lhits + (wave * CPW + c) * K;
+            const int id0 = wbase + lane * 128;
+            while (m0 != 0ull && pos < K) {            // ascending index: trip by trip (lane), first strip, second strip
+                h[pos++] = id0 + (int)__builtin_ctzll(m0);
+                m0 &= m0 - 1ull;
+            }
+            while (m1 != 0ull && pos < K) {
+                h[pos++] = id0 + 64 + (int)__builtin_ctzll(m1);
+                m1 &= m1 - 1ull;
+            }
+            written[c] = s[c];
+            rec[c][0] = rec[c][1] = rec[c][2] = rec[c][3] = 0;
+        };
 
         while (true) {
             bool any = false;
@@ -149,55 +230,117 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
             if (!any) break;
 
             // ---- one sweep over the database for every active chain of this wave ----
+            wtrip = 0;
+            wbase = 0;
+            bool act[CPW];       // the chain has a query with free slots (wave-uniform)
+#pragma unroll
+            for (int c = 0; c < CPW; c++) act[c] = has[c] && s[c] < K;
             for (int c0 = 0; c0 < N; c0 += chunkN) {
                 const int cn = (N - c0) < chunkN ? (N - c0) : chunkN;
                 if (MULTI) {
                     __syncthreads();
-                    stage_cloud(dbi, c0, cn, chunkN, lds);
+                    stage_cloud(dbi, c0, cn, lds);
                     __syncthreads();
                 }
                 // two strips (128 database points) per trip, the pair of distances in one packed register: the subtractions,
                 // products and sums are v_pk_{add,mul}_f32 (IEEE per component, no contraction: the same roundings as the scalar
-                // form), so the arithmetic of a trip costs what one strip cost before
-                for (int base = 0; base < cn; base += 128) {
-                    bool open = false;   // some chain still has free slots
-#pragma unroll
-                    for (int c = 0; c < CPW; c++) open = open || (has[c] && s[c] < K);
-                    if (!open) break;
-                    const int k0 = base + lane, k1 = k0 + 64;
-                    const bool in0 = k0 < cn, in1 = k1 < cn;
-                    const int kk0 = in0 ? k0 : cn - 1, kk1 = in1 ? k1 : cn - 1;
-                    const f32x2 x = {lx[kk0], lx[kk1]}, y = {ly[kk0], ly[kk1]}, z = {lz[kk0], lz[kk1]};
+                // form).
+                if constexpr (DEFER) {
+                    // A trip only RECORDS its hit masks: lane t of four registers per chain holds the two 64-bit masks of trip t
+                    // of the current window of 64 trips (v_writelane; scalar popcounts keep the slot count), and the
+                    // ascending-index slot list is expanded from the masks once per window (flush_hits).  The arithmetic of the
+                    // CPW chains is unconditional and interleaved (no branch, no packed-math hazard nops); a chain without free
+                    // slots is masked out on the scalar side.  Round 3 counters at S3DIS level 0: 44 k VALU + 33 k SALU and
+                    // 13 branches per trip and wave before (per-trip slot computation, predicated LDS stores, bounds masks,
+                    // one branch nest per chain) -> DESIGN.md section 0.
+                    unsigned long long am[CPW];        // all ones while the chain's query has free slots
+                    bool open = false;
 #pragma unroll
                     for (int c = 0; c < CPW; c++) {
-                        if (has[c] && s[c] < K) {   // wave-uniform
+                        am[c] = act[c] ? ~0ull : 0ull;
+                        open = open || act[c];
+                    }
+                    for (int base = 0; open && base < cn; base += 128) {
+                        const float* sp = lds + (base >> 7) * 384 + lane;
+                        const f32x2 x = {sp[0], sp[64]}, y = {sp[128], sp[192]}, z = {sp[256], sp[320]};
+                        unsigned long long m0[CPW], m1[CPW], any = 0ull;
+#pragma unroll
+                        for (int c = 0; c < CPW; c++) {
                             const f32x2 dx = x - qx[c];
                             const f32x2 dy = y - qy[c];
                             const f32x2 dz = z - qz[c];
                             const f32x2 d2 = (dx * dx + dy * dy) + dz * dz;   // tf_nnquery_gpu.cu:45-46
-                            const bool hit0 = in0 && (d2.x < thr[c]);
-                            const bool hit1 = in1 && (d2.y < thr[c]);
-                            const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
-                            if ((m0 | m1) != 0ull) {
-                                // ascending index: the first strip's hits take their slots before the second strip's
-                                const int pos0 = s[c] + prefix_popc(m0);
-                                const int pos1 = s[c] + __popcll(m0) + prefix_popc(m1);
-                                if (DEFER) {
-                                    int* h = lhits + (wave * CPW + c) * K;
-                                    if (hit0 && pos0 < K) h[pos0] = c0 + k0;
-                                    if (hit1 && pos1 < K) h[pos1] = c0 + k1;
-                                } else {
+                            m0[c] = __builtin_amdgcn_ballot_w64(d2.x < thr[c]) & am[c];
+                            m1[c] = __builtin_amdgcn_ballot_w64(d2.y < thr[c]) & am[c];
+                            any |= m0[c] | m1[c];
+                        }
+                        if (any != 0ull) {
+#pragma unroll
+                            for (int c = 0; c < CPW; c++) {
+                                if ((m0[c] | m1[c]) != 0ull) {
+                                    rec[c][0] = write_lane(rec[c][0], (int)(unsigned)m0[c], wtrip);
+                                    rec[c][1] = write_lane(rec[c][1], (int)(unsigned)(m0[c] >> 32), wtrip);
+                                    rec[c][2] = write_lane(rec[c][2], (int)(unsigned)m1[c], wtrip);
+                                    rec[c][3] = write_lane(rec[c][3], (int)(unsigned)(m1[c] >> 32), wtrip);
+                                    s[c] += __popcll(m0[c]) + __popcll(m1[c]);
+                                    if (s[c] >= K) am[c] = 0ull;
+                                }
+                            }
+                            unsigned long long o = 0ull;
+#pragma unroll
+                            for (int c = 0; c < CPW; c++) o |= am[c];
+                            open = o != 0ull;
+                        }
+                        if (++wtrip == 64) {
+#pragma unroll
+                            for (int c = 0; c < CPW; c++) flush_hits(c);
+                            wtrip = 0;
+                            wbase = c0 + base + 128;
+                        }
+                    }
+                    // the window ends with the chunk
+#pragma unroll
+                    for (int c = 0; c < CPW; c++) {
+                        flush_hits(c);
+                        act[c] = has[c] && s[c] < K;
+                    }
+                    wtrip = 0;
+                    wbase = c0 + cn;
+                } else {
+                    // K too large for LDS slot lists: slots are computed and written from inside the scan
+                    for (int base = 0; base < cn; base += 128) {
+                        bool open = false;   // some chain still has free slots
+#pragma unroll
+                        for (int c = 0; c < CPW; c++) open = open || act[c];
+                        if (!open) break;
+                        const float* sp = lds + (base >> 7) * 384 + lane;
+                        const f32x2 x = {sp[0], sp[64]}, y = {sp[128], sp[192]}, z = {sp[256], sp[320]};
+#pragma unroll
+                        for (int c = 0; c < CPW; c++) {
+                            if (act[c]) {   // wave-uniform
+                                const f32x2 dx = x - qx[c];
+                                const f32x2 dy = y - qy[c];
+                                const f32x2 dz = z - qz[c];
+                                const f32x2 d2 = (dx * dx + dy * dy) + dz * dz;   // tf_nnquery_gpu.cu:45-46
+                                const unsigned long long m0 = __builtin_amdgcn_ballot_w64(d2.x < thr[c]);
+                                const unsigned long long m1 = __builtin_amdgcn_ballot_w64(d2.y < thr[c]);
+                                if ((m0 | m1) != 0ull) {
+                                    // ascending index: the first strip's hits take their slots before the second strip's
+                                    const bool hit0 = (m0 >> lane) & 1ull, hit1 = (m1 >> lane) & 1ull;
+                                    const int pos0 = s[c] + prefix_popc(m0);
+                                    const int pos1 = s[c] + __popcll(m0) + prefix_popc(m1);
                                     const size_t o = ((size_t)i * M + j[c]) * K;
                                     if (hit0 && pos0 < K) {
-                                        nnIndex[o + pos0] = c0 + k0;
+                                        nnIndex[o + pos0] = c0 + base + lane;
                                         nnDist[o + pos0] = sqrtf(sqrtf(d2.x));   // :47 then :54 — sqrt of the distance
                                     }
                                     if (hit1 && pos1 < K) {
-                                        nnIndex[o + pos1] = c0 + k1;
+                                        nnIndex[o + pos1] = c0 + base + 64 + lane;
                                         nnDist[o + pos1] = sqrtf(sqrtf(d2.y));
                                     }
+                                    s[c] += __popcll(m0) + __popcll(m1);
+                                    act[c] = s[c] < K;
                                 }
-                                s[c] += __popcll(m0) + __popcll(m1);
                             }
                         }
                     }
@@ -209,6 +352,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
             for (int c = 0; c < CPW; c++) {
                 if (has[c]) {
                     r[c] = (float)((double)r[c] + 0.05);
+                    kpos[c]++;
                     passes[c]++;
                     if (s[c] > 0 || passes[c] >= SPH3D_MAX_GROWTH_PASSES) {
                         const int cnt = s[c] < K ? s[c] : K;
@@ -250,15 +394,16 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
                         j[c] += kRefBlock;
                         has[c] = j[c] < M;
                         s[c] = 0;
+                        written[c] = 0;
                         passes[c] = 0;
-                        if (fixed) r[c] = radius0;          // fixed-radius mode: every query starts from the nominal radius
+                        if (fixed) { r[c] = radius0; kpos[c] = 0; }         // fixed-radius mode: every query starts from the nominal radius
                         if (has[c]) {
                             qx[c] = qi[j[c] * 3];
                             qy[c] = qi[j[c] * 3 + 1];
                             qz[c] = qi[j[c] * 3 + 2];
                         }
                     }
-                    if (has[c]) thr[c] = range_threshold(r[c]);
+                    if (has[c]) thr[c] = threshold_of(c);
                 }
             }
         }
@@ -325,7 +470,7 @@ static int launch_sphere(int B, int N, int M, int K, float radius, int chunkN,
     const int nb = B < kRefGrid ? B : kRefGrid;
     const int nt = M < kRefBlock ? M : kRefBlock;
     const int groups = (nt + kWavesPerWG * CPW - 1) / (kWavesPerWG * CPW);
-    const size_t lds = (size_t)3 * chunkN * sizeof(float) + (DEFER ? hits_bytes(CPW, K) : 0);
+    const size_t lds = (size_t)3 * ((chunkN + 127) & ~127) * sizeof(float) + (DEFER ? hits_bytes(CPW, K) : 0) + kThrTable * sizeof(float);
     if constexpr (DEFER) {
         if (fuse != nullptr) {
             auto kernf = nnquery_sphere_kernel<CPW, MULTI, DEFER, true>;
@@ -369,13 +514,13 @@ static int sphere_neighbor(int fixed, int B, int N, int M, int nn_sample, float 
     const int cpw = chains >= 256LL * kWavesPerWG * 4 ? 4 : (chains >= 256LL * kWavesPerWG * 2 ? 2 : 1);
     // LDS: the cloud chunk (12 B per point) next to the deferred hit lists
     size_t hb = hits_bytes(cpw, nn_sample);
-    int maxChunk = (int)((160 * 1024 - hb) / 12) & ~63;
+    int maxChunk = (int)((160 * 1024 - kThrTable * 4 - hb) / 12) & ~127;      // whole trips of 128 points
     if (maxChunk > kMaxChunk) maxChunk = kMaxChunk;
     int chunkN = N < maxChunk ? N : maxChunk;
     const bool multi = N > chunkN;
     if (multi) {
         hb = hits_bytes(1, nn_sample);
-        maxChunk = (int)((160 * 1024 - hb) / 12) & ~63;
+        maxChunk = (int)((160 * 1024 - kThrTable * 4 - hb) / 12) & ~127;
         if (maxChunk > kMaxChunk) maxChunk = kMaxChunk;
         chunkN = maxChunk;
     }

@@ -284,6 +284,21 @@ def separable_conv3d(inputs,
                                                    shape=[kernel_size, num_in_channels, depth_multiplier],
                                                    use_xavier=use_xavier, stddev=stddev,
                                                    with_decay=weight_decay)
+    if (FUSE_SEPARABLE_INFERENCE and is_training is not None and not bool(is_training) and not torch.is_grad_enabled()
+            and (activation_fn is elu or activation_fn is None)
+            and tf_conv3d.separable_fused_supported(inputs, depthwise_kernel, nn_index, num_out_channels)):
+        # inference: the whole layer in one kernel, the depthwise tensor never written (csrc/sepconv.hip)
+        store = get_variable_store()
+        kernel = _variable_with_weight_decay(scope + '/weights', shape=[num_in_channels * depth_multiplier, num_out_channels],
+                                             use_xavier=use_xavier, stddev=stddev, with_decay=weight_decay)
+        biases = store.get_variable(scope + '/biases', [num_out_channels], _constant(0.0)) if with_bias else None
+        scale = shift = None
+        if with_bn:
+            gamma, beta, moving_mean, moving_var = _bn_variables(store, scope + '/bn', num_out_channels)
+            scale = gamma * torch.rsqrt(moving_var + 1e-3)
+            shift = beta - moving_mean * scale
+        return tf_conv3d.separable_conv3d_fused(inputs, depthwise_kernel, kernel, nn_index, nn_count, filt_index, bias=biases,
+                                                elu=activation_fn is elu, scale=scale, shift=shift)
     outputs = tf_conv3d.depthwise_conv3d(inputs, depthwise_kernel, nn_index, nn_count, filt_index)
 
     batch_size = outputs.shape[0]
@@ -361,6 +376,7 @@ def unpool3d(inputs, nn_index, nn_count, nn_dist, scope, method):
 
 
 FUSE_GEMM_BN = True    # the statistics of that tail from the GEMM's epilogue where the shape allows (tf_norm.gemm_elu_batch_norm)
+FUSE_SEPARABLE_INFERENCE = True   # is_training=False under torch.no_grad(): separable_conv3d as ONE kernel (tf_conv3d.separable_conv3d_fused)
 FUSE_ELU_BN = True     # fused sph3d::elu_bn for the ELU -> BN tail (same variables / moving statistics as the unfused ops)
 
 

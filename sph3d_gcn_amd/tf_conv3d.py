@@ -155,3 +155,51 @@ def depthwise_conv3d(input, filter, nn_index, nn_count, bin_index):
 
 def depthwise_conv3d_grad(input, filter, grad_output, nn_index, nn_count, bin_index):
     return _depthwise_conv3d_grad_impl(input, filter, grad_output, nn_index, nn_count, bin_index)
+
+
+# ---- the whole separable layer in one kernel, inference only (csrc/sepconv.hip) ---------------------------
+def separable_fused_supported(input, filter, nn_index, num_out_channels):
+    """shapes sph3d_separable_conv3d_fused covers (C <= 128, C*r <= 256, Cout <= 128 in multiples of 16)"""
+    if not (input.is_cuda and input.dim() == 3 and filter.dim() == 3 and nn_index.dim() == 3):
+        return False
+    return bool(_lib.lib().sph3d_separable_conv3d_fused_supported(input.shape[1], filter.shape[0], input.shape[2],
+                                                                  filter.shape[2], nn_index.shape[2], int(num_out_channels)))
+
+
+def _separable_conv3d_fused_impl(input: torch.Tensor, filter: torch.Tensor, weights: torch.Tensor, bias: torch.Tensor,
+                                 scale: torch.Tensor, shift: torch.Tensor, act: int, nn_index: torch.Tensor,
+                                 nn_count: torch.Tensor, bin_index: torch.Tensor) -> torch.Tensor:
+    _lib.require_device(input, filter, weights, nn_index, nn_count, bin_index)
+    _check_conv(input, filter, nn_index, nn_count, bin_index)
+    input, filter, weights = _lib.f32(input), _lib.f32(filter), _lib.f32(weights)
+    nn_index, nn_count, bin_index = _lib.i32(nn_index), _lib.i32(nn_count), _lib.i32(bin_index)
+    B, N, C = input.shape
+    F, _, r = filter.shape
+    M, K = nn_index.shape[1], nn_index.shape[2]
+    Cout = weights.shape[1]
+    if weights.shape[0] != C * r:
+        raise ValueError("pointwise weights should be [C*r, Cout]")
+    opt = [None if t is None or t.numel() == 0 else _lib.f32(t) for t in (bias, scale, shift)]
+    out = torch.empty((B, M, Cout), dtype=torch.float32, device=input.device)
+    _lib.check(_lib.lib().sph3d_separable_conv3d_fused(B, N, M, F, C, r, K, Cout, int(act), _lib.ptr(nn_index),
+                                                       _lib.ptr(nn_count), _lib.ptr(bin_index), _lib.ptr(input),
+                                                       _lib.ptr(filter), _lib.ptr(weights), _lib.ptr(opt[0]), _lib.ptr(opt[1]),
+                                                       _lib.ptr(opt[2]), _lib.ptr(out), _lib.stream_ptr()))
+    return out
+
+
+_separable_conv3d_fused = torch.library.custom_op("sph3d::separable_conv3d_fused", mutates_args=())(_separable_conv3d_fused_impl)
+
+
+@_separable_conv3d_fused.register_fake
+def _(input, filter, weights, bias, scale, shift, act, nn_index, nn_count, bin_index):
+    return input.new_empty((input.shape[0], nn_index.shape[1], weights.shape[1]))
+
+
+def separable_conv3d_fused(input, filter, weights, nn_index, nn_count, bin_index, bias=None, elu=True, scale=None, shift=None):
+    """elu?(depthwise_conv3d(input, filter) @ weights + bias) * scale + shift  -> [B, M, Cout], no gradient (inference):
+    the depthwise tensor stays in LDS.  bias / scale / shift: [Cout] or None."""
+    e = input.new_empty(0)
+    with torch.no_grad():
+        return _separable_conv3d_fused_impl(input, filter, weights, e if bias is None else bias, e if scale is None else scale,
+                                            e if shift is None else shift, 1 if elu else 0, nn_index, nn_count, bin_index)

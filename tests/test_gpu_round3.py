@@ -360,3 +360,110 @@ def test_fps_large_clouds_cooperative_kernel_bitexact(dev, B, n, m):
     want = oracle.farthest_point_sample(m, xyz)
     np.testing.assert_array_equal(got, want)
     print("\nFPS %d x %d -> %d: %.1f ms" % (B, n, m, dt * 1e3))
+
+
+# ---- fused separable convolution for inference (csrc/sepconv.hip) -----------------------------------------
+# (kind, B, N, M, radius, K, kernel, C, r, Cout)
+SEPCONV_CASES = [
+    ("s3dis", 2, 2048, 2048, 0.1, 64, [8, 2, 2], 64, 2, 64),        # the S3DIS level-0 layer shape
+    ("s3dis", 8, 1024, 1024, 0.15, 64, [8, 2, 2], 128, 2, 128),     # B % 8 == 0: XCD-affine tiles; 16 k-groups, 16 GEMM waves
+    ("uniform", 3, 700, 333, 0.15, 32, [8, 2, 2], 128, 1, 64),      # M < N (an inter-level graph), ragged last tile
+    ("uniform", 2, 500, 500, 0.15, 24, [4, 2, 1], 36, 2, 16),       # C*r = 72: k padded to 80; 9 bins; one column block
+    ("modelnet", 1, 1500, 1500, 0.1, 48, [8, 2, 3], 8, 1, 32),      # 49 bins, narrow input
+    ("uniform", 9, 257, 257, 0.2, 64, [8, 2, 2], 32, 2, 96),
+]
+
+
+@pytest.mark.parametrize("tail", ["bias+elu+bn", "bias", "elu", "none"])
+@pytest.mark.parametrize("case", SEPCONV_CASES, ids=lambda c: "%s-B%d-N%d-M%d-C%d-r%d-Co%d" % (c[0], c[1], c[2], c[3], c[7], c[8], c[9]))
+def test_fused_inference_separable_conv_vs_oracle_and_separate_kernels(dev, case, tail):
+    kind, B, N, M, radius, K, kernel, C, r, Cout = case
+    F = kernel[0] * kernel[1] * kernel[2] + 1
+    xyz = {"s3dis": lambda: synth.s3dis_batch(7, B, N)[0], "modelnet": lambda: synth.modelnet_batch(7, B, N),
+           "uniform": lambda: synth.uniform_cloud(7, B, N, 1.0)}[kind]()
+    xyz = _t(xyz, dev)
+    q = xyz[:, :M].contiguous()
+    idx, cnt, dst = tf_nnquery.build_sphere_neighbor(xyz, q, radius, None, K)
+    filt = tf_buildkernel.spherical_kernel(xyz, q, idx, cnt, dst, radius, kernel)
+    rng = np.random.RandomState(C * 7 + Cout)
+    x = rng.randn(B, N, C).astype(np.float32)
+    dw = rng.randn(F, C, r).astype(np.float32)
+    w = (rng.randn(C * r, Cout) / np.sqrt(C * r)).astype(np.float32)
+    bias = rng.randn(Cout).astype(np.float32) if "bias" in tail else None
+    scale = (0.5 + rng.rand(Cout)).astype(np.float32) if "bn" in tail else None
+    shift = rng.randn(Cout).astype(np.float32) if "bn" in tail else None
+    elu = "elu" in tail
+    assert tf_conv3d.separable_fused_supported(_t(x, dev), _t(dw, dev), idx, Cout)
+    out = tf_conv3d.separable_conv3d_fused(_t(x, dev), _t(dw, dev), _t(w, dev), idx, cnt, filt,
+                                           bias=None if bias is None else _t(bias, dev), elu=elu,
+                                           scale=None if scale is None else _t(scale, dev),
+                                           shift=None if shift is None else _t(shift, dev))
+    assert out.shape == (B, M, Cout)
+
+    def tail_of(d):                                  # float64 restatement of utils/sph3gcn_util.py:146-161 (inference)
+        y = d.astype(np.float64).reshape(-1, C * r) @ w.astype(np.float64)
+        if bias is not None:
+            y = y + bias
+        if elu:
+            y = np.where(y > 0, y, np.expm1(np.minimum(y, 0)))
+        if scale is not None:
+            y = y * scale + shift
+        return y.reshape(B, M, Cout)
+
+    want_o = tail_of(oracle.depthwise_conv3d(x, dw, _n(idx), _n(cnt), _n(filt)))
+    want_k = tail_of(_n(tf_conv3d.depthwise_conv3d(_t(x, dev), _t(dw, dev), idx, cnt, filt)))
+    mag = max(1.0, float(np.abs(want_o).max()))
+    np.testing.assert_allclose(_n(out) / mag, want_o / mag, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(_n(out) / mag, want_k / mag, rtol=2e-5, atol=2e-5)
+
+
+def test_fused_inference_separable_conv_rejects_uncovered_shapes(dev):
+    x, dw = torch.randn(1, 64, 256, device=dev), torch.randn(33, 256, 2, device=dev)
+    idx = torch.zeros(1, 64, 8, dtype=torch.int32, device=dev)
+    cnt = torch.ones(1, 64, dtype=torch.int32, device=dev)
+    assert not tf_conv3d.separable_fused_supported(x, dw, idx, 128)          # C = 256
+    assert not tf_conv3d.separable_fused_supported(x[..., :64], dw[:, :64], idx, 200)
+    with pytest.raises(RuntimeError, match="not covered"):
+        tf_conv3d.separable_conv3d_fused(x, dw, torch.randn(512, 128, device=dev), idx, cnt, idx)
+
+
+@pytest.mark.parametrize("with_bn", [True, False])
+def test_separable_layer_inference_fused_equals_layer_by_layer(dev, with_bn):
+    """s3g_util.separable_conv3d(is_training=False) under no_grad runs the one-kernel layer: same variables in the same order,
+    same output as the op-by-op layer (moving statistics away from their initial values)"""
+    xyz = _t(synth.s3dis_batch(3, 2, 1024, extent=(1.0, 1.0, 1.5))[0], dev)
+    idx, cnt, dst, filt = s3g_util.build_intra_graph(xyz, 0.15, 32, [8, 2, 2])
+    feat = torch.randn(2, 1024, 64, device=dev)
+
+    def run(fused):
+        s3g_util.FUSE_SEPARABLE_INFERENCE = fused
+        store = s3g_util.VariableStore(device=dev, seed=5)
+        with s3g_util.variable_store(store):                 # a training step creates the variables and moves the statistics
+            s3g_util.separable_conv3d(feat, 128, 33, 2, 'c1', idx, cnt, filt, with_bn=with_bn, with_bias=True, is_training=True)
+        with torch.no_grad():
+            for n, p in store.params.items():
+                if 'biases' in n or 'beta' in n:
+                    p.add_(0.3)
+            with s3g_util.variable_store(store):
+                out = s3g_util.separable_conv3d(feat, 128, 33, 2, 'c1', idx, cnt, filt, with_bn=with_bn, with_bias=True,
+                                                is_training=False)
+        return out, list(store.params.keys())
+
+    from sph3d_gcn_amd import _lib
+
+    def counted(fused):
+        _lib.timing_start()
+        try:
+            res = run(fused)
+        finally:
+            names = [c[0] for c in _lib.timing_stop()]
+        return res, names.count("sph3d_separable_conv3d_fused")
+
+    try:
+        (out_f, names_f), n_f = counted(True)
+        (out_u, names_u), n_u = counted(False)
+    finally:
+        s3g_util.FUSE_SEPARABLE_INFERENCE = True
+    assert (n_f, n_u) == (1, 0)
+    assert names_f == names_u
+    np.testing.assert_allclose(_n(out_f), _n(out_u), rtol=2e-5, atol=2e-5)
