@@ -46,6 +46,9 @@ NN_CASES = [
     ("uniform", 4, 1500, 3000, 0.05, 16),      # decoder-like: db != query, isolated queries need growth passes
     ("uniform", 1, 13000, 200, 0.05, 32),      # N > one LDS chunk (multi-chunk path)
     ("uniform", 2, 500, 40, 0.01, 70),         # K > 64, many growth passes
+    ("uniform", 1, 10000, 300, 0.04, 32),      # one LDS chunk of 79 trips: the hit-mask window (64 trips) is flushed inside a chunk
+    ("uniform", 1, 300, 70000, 0.05, 8),       # 69 queries per chain: positions of the radius sequence beyond the tabulated 64
+    ("uniform", 2, 700, 90, 0.3, 200),         # K = 200: the slot lists do not fit LDS, slots are written from inside the scan
 ]
 
 
