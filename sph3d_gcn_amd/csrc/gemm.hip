@@ -30,6 +30,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 as_v4(const float4 v) { f32x4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
 
+#ifndef SPH3D_GEMM_EXP
+#define SPH3D_GEMM_EXP 0      // diagnostic builds only (wrong results): 1 no global loads, 2 no LDS stores, 4 no barrier in the k loop
+#endif
 #ifndef SPH3D_GEMM_SETPRIO
 #define SPH3D_GEMM_SETPRIO 1
 #endif
@@ -166,6 +169,63 @@ struct Stage {
     }
 };
 
+// ---- LDS-DMA staging (unguarded whole tiles, BK = 16) -------------------------------------------------------------------
+// global_load_lds_dwordx4 writes a wave's 64 x 16 B straight into LDS at (uniform base + lane * 16): no prefetch registers,
+// no ds_write, no vmcnt wait in front of a store — phase-skip timing of the register-staged loop (tools/gpu_gemm_exp.sh) put
+// 16 of the 93 us of the level-0 forward product into exactly that (global-load issue 6, LDS stores 7, barrier skew 3).
+// The LDS image is therefore the MEMORY order of the tile, 16-byte granule by granule, and the only freedom left is WHICH
+// global granule a lane fetches into its slot.  That freedom carries the bank swizzles:
+//   k-contiguous operand ([row][16 k], 4 granules per row): slot = kq ^ ((row >> 2) & 3).  A lane's fragment for four MFMA
+//       steps is still one ds_read_b128 at granule row*4 + ((2g + lk) ^ swizzle); the 16 rows of a b128 phase hit 16
+//       distinct bank quads (rows r, r+4, r+8, r+12 would collide at stride 64 B without it).
+//   row-contiguous operand ([16 k][BT rows]): element (k, row) sits at k*BT + (row ^ (bit 2 of k) << 5).  A lane reads its
+//       four steps as four ds_read_b32 (k = 8g + 4lk + s, so bit 2 of k is the lane half lk): the two lane halves then use
+//       opposite halves of the 64 banks instead of the same 32.
+template <bool KM, int BT>
+struct Dma {
+    static constexpr int GR = BT * 4;                 // 16-byte granules of a BT x 16 tile
+    static constexpr int NI = GR / 256;               // wave instructions per wave (4 waves), 64 granules each
+    static_assert(GR % 256 == 0, "tile must split into whole wave instructions");
+    unsigned voff[NI];
+    __device__ __forceinline__ void init(int ld)
+    {
+        const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const int p = (wave * NI + i) * 64 + lane;
+            if (KM) {
+                const int row = p >> 2, kq = (p & 3) ^ ((row >> 2) & 3);
+                voff[i] = (unsigned)(row * ld + kq * 4);
+            } else {
+                const int k = p / (BT / 4), mq = (p % (BT / 4)) ^ (((k >> 2) & 1) << 3);
+                voff[i] = (unsigned)(k * ld + mq * 4);
+            }
+        }
+    }
+    // base: workgroup-uniform address of the tile's first element; image: LDS address of the tile image
+    __device__ __forceinline__ void issue(const float* __restrict__ base, float* image) const
+    {
+        const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff[i]),
+                                             (__attribute__((address_space(3))) void*)(image + (wave * NI + i) * 256), 16, 0, 0);
+        }
+    }
+    // fragment of the lane for the four MFMA steps of k-group g: row = tile row of the lane, lk = lane half
+    static __device__ __forceinline__ f32x4 frag(const float* image, int row, int g, int lk)
+    {
+        if (KM) return *reinterpret_cast<const f32x4*>(image + ((row << 2) + ((2 * g + lk) ^ ((row >> 2) & 3))) * 4);
+        const float* q = image + (8 * g + 4 * lk) * BT + (row ^ (lk << 5));
+        return f32x4{q[0], q[BT], q[2 * BT], q[3 * BT]};
+    }
+};
+
+#ifndef SPH3D_GEMM_DMA
+#define SPH3D_GEMM_DMA 1
+#endif
+constexpr int cmax_i(int a, int b) { return a > b ? a : b; }
+
 // k assignment inside a group of 8 consecutive k: MFMA step s (0..3) multiplies k = 8g + s (lanes 0..31) with
 // k = 8g + 4 + s (lanes 32..63).  Any pairing is legal (the sum over k is what matters, A and B use the same one);
 // this one makes a lane's operands for the 4 steps of a group ONE float4 at lds[row][8g + 4*(lane>>5)].
@@ -186,8 +246,10 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? 4 : 2) void gemm_f32_mf
     using SA = Stage<AK, BMT, BK>;
     using SB = Stage<BKM, BN, BK>;
     constexpr int LDK = BK + 4;
-    __shared__ __attribute__((aligned(16))) float lds[2 * (SA::LDS_FLOATS + SB::LDS_FLOATS)];
+    constexpr bool DMA = SPH3D_GEMM_DMA != 0 && !GUARD && BK == 16;       // LDS-DMA staging (see Dma)
     constexpr int WM = BMT / 2, WN = BN / 2;     // wave sub-tile
+    constexpr int LDSF = DMA ? cmax_i(2 * (BMT + BN) * BK, 4 * 32 * (WN + 4)) : 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];
     constexpr int TM = WM / 32, TN = WN / 32;    // MFMA tiles per wave
 
     const int tiles_n = (N + BN - 1) / BN;
@@ -212,6 +274,57 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? 4 : 2) void gemm_f32_mf
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
+    if constexpr (DMA) {
+        constexpr int ABUF = BMT * BK, BUFD = (BMT + BN) * BK;          // buffer b: A image at lds + b*BUFD, B image after it
+        Dma<AK, BMT> da;
+        Dma<BKM, BN> db;
+        da.init(lda);
+        db.init(ldb);
+        const float* abase = AK ? A + (size_t)m0 * lda + k_begin : A + (size_t)k_begin * lda + m0;
+        const float* bbase = BKM ? B + (size_t)n0 * ldb + k_begin : B + (size_t)k_begin * ldb + n0;
+        const size_t astep = AK ? (size_t)BK : (size_t)BK * lda;
+        const size_t bstep = BKM ? (size_t)BK : (size_t)BK * ldb;
+        da.issue(abase, lds);
+        db.issue(bbase, lds + ABUF);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int buf = 0;
+        for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+            const bool more = (k0 + BK) < k_end;
+            if (more) {                   // tile t+1 -> the other buffer (nobody reads it during this iteration), no registers
+                abase += astep;
+                bbase += bstep;
+                da.issue(abase, lds + (buf ^ 1) * BUFD);
+                db.issue(bbase, lds + (buf ^ 1) * BUFD + ABUF);
+            }
+            const float* ca = lds + buf * BUFD;
+            const float* cb = ca + ABUF;
+            if (kSetPrio) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+            for (int g = 0; g < BK / 8; g++) {
+                f32x4 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; i++) af[i] = Dma<AK, BMT>::frag(ca, wm + i * 32 + li, g, lk);
+#pragma unroll
+                for (int j = 0; j < TN; j++) bf[j] = Dma<BKM, BN>::frag(cb, wn + j * 32 + li, g, lk);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) {
+#pragma unroll
+                    for (int i = 0; i < TM; i++)
+#pragma unroll
+                        for (int j = 0; j < TN; j++) {
+                            const float av = s4 == 0 ? af[i].x : (s4 == 1 ? af[i].y : (s4 == 2 ? af[i].z : af[i].w));
+                            const float bv = s4 == 0 ? bf[j].x : (s4 == 1 ? bf[j].y : (s4 == 2 ? bf[j].z : bf[j].w));
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                        }
+                }
+            }
+            if (kSetPrio) __builtin_amdgcn_s_setprio(0);
+            if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of tile t+1 has landed
+            __syncthreads();              // ONE barrier per k-tile
+            buf ^= 1;
+        }
+    } else {
     SA sa;
     SB sb;
     constexpr int BUF = SA::LDS_FLOATS + SB::LDS_FLOATS;     // buffer b: A image at lds + b*BUF, B image after it
@@ -235,7 +348,7 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? 4 : 2) void gemm_f32_mf
     int buf = 0;
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         const bool more = (k0 + BK) < k_end;
-        if (more) {                       // global -> registers for tile t+1 while tile t is multiplied
+        if (more && !(SPH3D_GEMM_EXP & 1)) {                       // global -> registers for tile t+1 while tile t is multiplied
             if (GUARD) {
                 sa.template load<GUARD>(A, lda, m0, k0 + BK, M, k_end, a_vec);
                 sb.template load<GUARD>(B, ldb, n0, k0 + BK, N, k_end, b_vec);
@@ -269,12 +382,14 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? 4 : 2) void gemm_f32_mf
             }
         }
         if (kSetPrio) __builtin_amdgcn_s_setprio(0);
-        if (more) {                       // the other buffer: nobody reads it during this iteration
+        if (more && !(SPH3D_GEMM_EXP & 2)) {                       // the other buffer: nobody reads it during this iteration
             sa.store(lds + (buf ^ 1) * BUF);
             sb.store(lds + (buf ^ 1) * BUF + SA::LDS_FLOATS);
         }
-        __syncthreads();                  // ONE barrier per k-tile
+        if (!(SPH3D_GEMM_EXP & 4)) __syncthreads();                  // ONE barrier per k-tile
         buf ^= 1;
+    }
+
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
@@ -284,7 +399,7 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? 4 : 2) void gemm_f32_mf
         // loop's last barrier) and write it back as float4 rows: WN/4 lanes cover one row, 16 B per lane, instead of
         // sixteen 4-byte stores per MFMA tile (the scalar epilogue was store-issue-bound: ~25 % of the kernel)
         constexpr int EP = WN + 4;                           // padded row stride (floats)
-        static_assert(4 * 32 * EP <= 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS), "epilogue staging must fit the operand LDS");
+        static_assert(4 * 32 * EP <= LDSF, "epilogue staging must fit the operand LDS");
         float* stage = lds + wave * (32 * EP);
         constexpr int LPR = WN / 4;                          // lanes per row
         constexpr int RPI = 64 / LPR;                        // rows per store instruction
