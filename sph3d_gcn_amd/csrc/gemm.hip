@@ -224,6 +224,9 @@ struct Dma {
 #ifndef SPH3D_GEMM_DMA
 #define SPH3D_GEMM_DMA 1
 #endif
+#ifndef SPH3D_GEMM_WGS
+#define SPH3D_GEMM_WGS 5      // workgroups per CU the unguarded BK = 16 kernels are built for
+#endif
 constexpr int cmax_i(int a, int b) { return a > b ? a : b; }
 
 // k assignment inside a group of 8 consecutive k: MFMA step s (0..3) multiplies k = 8g + s (lanes 0..31) with
@@ -238,7 +241,7 @@ constexpr int cmax_i(int a, int b) { return a > b ? a : b; }
 // per half tile of rows and per column, sum z and sum z*z with z = elu(y) — the partial sums the fused ELU+BN op's statistics
 // pass would otherwise produce by reading Y once more (norm.hip: norm_reduce_kernel, same [block][2][C] layout).
 template <bool AK, bool BKM, int BMT, int BN, int BK, bool SPLITK, bool GUARD, bool STATS = false>
-__global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? 4 : 2) void gemm_f32_mfma(int M, int N, int Kd, const float* __restrict__ A, int lda,
+__global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? (SPH3D_GEMM_DMA != 0 && SPH3D_GEMM_WGS > 4 ? SPH3D_GEMM_WGS : 4) : 2) void gemm_f32_mfma(int M, int N, int Kd, const float* __restrict__ A, int lda,
                                                      const float* __restrict__ B, int ldb, float* __restrict__ Cmat,
                                                      int ldc, const float* __restrict__ bias, int act, int kchunk,
                                                      float* __restrict__ stats = nullptr)
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? 4 : 2) void gemm_f32_mf
     constexpr int LDK = BK + 4;
     constexpr bool DMA = SPH3D_GEMM_DMA != 0 && !GUARD && BK == 16;       // LDS-DMA staging (see Dma)
     constexpr int WM = BMT / 2, WN = BN / 2;     // wave sub-tile
-    constexpr int LDSF = DMA ? cmax_i(2 * (BMT + BN) * BK, 4 * 32 * (WN + 4)) : 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
+    constexpr int LDSF = DMA ? cmax_i(2 * (BMT + BN) * BK, 4 * 32 * (WN == 64 ? WN : WN + 4)) : 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
     __shared__ __attribute__((aligned(16))) float lds[LDSF];
     constexpr int TM = WM / 32, TN = WN / 32;    // MFMA tiles per wave
 
@@ -398,7 +401,11 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? 4 : 2) void gemm_f32_mf
         // whole tiles: stage each wave's 32 x WN slab through its own LDS region (the operand buffers are free after the
         // loop's last barrier) and write it back as float4 rows: WN/4 lanes cover one row, 16 B per lane, instead of
         // sixteen 4-byte stores per MFMA tile (the scalar epilogue was store-issue-bound: ~25 % of the kernel)
-        constexpr int EP = WN + 4;                           // padded row stride (floats)
+        // row stride of the staging slab (floats): padded by 4, or — LDS-DMA kernels, whose operand buffers are exactly 32 KB at
+        // 128 x 128: FIVE workgroups per CU — unpadded with the column XOR-ed by 32 * (bit 2 of the row) = the lane half lk, so
+        // that the two lane halves of a store (rows 4 apart) and the four rows of a float4 read still use distinct banks
+        constexpr bool EPX = DMA && WN == 64;
+        constexpr int EP = EPX ? WN : WN + 4;
         static_assert(4 * 32 * EP <= LDSF, "epilogue staging must fit the operand LDS");
         float* stage = lds + wave * (32 * EP);
         constexpr int LPR = WN / 4;                          // lanes per row
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? 4 : 2) void gemm_f32_mf
                 for (int e = 0; e < 16; e++) {
                     float v = acc[i][j][e] + bv;
                     if (!SPLITK && act == 1) v = v > 0.f ? v : expm1f(v);
-                    stage[((e & 3) + 8 * (e >> 2) + 4 * lk) * EP + j * 32 + li] = v;
+                    stage[((e & 3) + 8 * (e >> 2) + 4 * lk) * EP + ((j * 32 + li) ^ (EPX ? (lk << 5) : 0))] = v;
                 }
             }
             // same wave wrote and reads: LDS ops of one wave complete in order, no barrier needed
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? 4 : 2) void gemm_f32_mf
             for (int it = 0; it < 32 / RPI; it++) {
                 const int r = it * RPI + lane / LPR;
                 const int c4 = (lane % LPR) * 4;
-                const float4 v = *reinterpret_cast<const float4*>(&stage[r * EP + c4]);
+                const float4 v = *reinterpret_cast<const float4*>(&stage[r * EP + (c4 ^ (EPX ? (((r >> 2) & 1) << 5) : 0))]);
                 *reinterpret_cast<float4*>(&Cout[(size_t)(m0 + wm + i * 32 + r) * ldc + n0 + wn + c4]) = v;
             }
         }
@@ -567,7 +574,7 @@ static void tn_plan(int R, int Cin, int Cout, int& bn, int& tiles, int& nsplit, 
     // ~2 workgroups per CU in total: measured round 2 over the 13 S3DIS shapes, 512 workgroups 0.97 ms against 1.10 ms
     // with 1024 (twice the partial tiles to write and re-read, half the k-loop to amortise prologue and epilogue) and
     // 1.11 ms with 256
-    int want = (512 + tiles - 1) / tiles;
+    int want = (512 + tiles - 1) / tiles;      // (re-measured with the LDS-DMA kernel: 512 -> 2.25 ms over the 13 shapes, 768 2.46, 1024 2.31, 2048 2.28)
     int maxsplit = (R + 255) / 256;                   // at least 256 rows of k per split
     nsplit = want < maxsplit ? want : maxsplit;
     if (nsplit < 1) nsplit = 1;

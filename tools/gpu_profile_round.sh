@@ -45,3 +45,17 @@ for cfg in "nn:KIND=nn SHAPE=131072,256,128" "nt:KIND=nt SHAPE=131072,256,128" "
   bash tools/gpu_pmc3.sh ${TAG}_mfma_$name tools/exp_gemm_pmc.py "$env" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE" gemm | tail -3
 done
 ls $OUT | grep "^$TAG" | head -60
+# neighbour search (level-0 plain search, 16 x 8192, K = 64): instruction mix of the in-tree kernel and, when a library built
+# with the previous scan is present (sph3d_gcn_amd/csrc/libsph3d_nnbefore.so), of that one
+for cfg in "after:" "before:SPH3D_LIB=$GRAFT_REPO_ROOT/sph3d_gcn_amd/csrc/libsph3d_nnbefore.so"; do
+  name=${cfg%%:*}; env=${cfg#*:}
+  [ "$name" = "before" ] && [ ! -f $GRAFT_REPO_ROOT/sph3d_gcn_amd/csrc/libsph3d_nnbefore.so ] && continue
+  bash tools/gpu_pmc3.sh ${TAG}_nnquery_$name tools/exp_nn_pmc.py "NN=plain $env" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH GRBM_GUI_ACTIVE" nnquery | tail -2
+done
+# one flat CSV per counter pass next to the summaries (what gets copied into profiles/)
+for d in $OUT/pmc_${TAG}_*; do
+  [ -d "$d" ] || continue
+  f=$(find $d -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && cp $f $OUT/$(basename $d | sed "s/^pmc_${TAG}_/${TAG}_pmc_/").csv
+done
+ls $OUT | grep "^$TAG" | head -80
