@@ -244,7 +244,7 @@ template <bool AK, bool BKM, int BMT, int BN, int BK, bool SPLITK, bool GUARD, b
 __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? (SPH3D_GEMM_DMA != 0 && SPH3D_GEMM_WGS > 4 ? SPH3D_GEMM_WGS : 4) : 2) void gemm_f32_mfma(int M, int N, int Kd, const float* __restrict__ A, int lda,
                                                      const float* __restrict__ B, int ldb, float* __restrict__ Cmat,
                                                      int ldc, const float* __restrict__ bias, int act, int kchunk,
-                                                     float* __restrict__ stats = nullptr)
+                                                     float* __restrict__ stats = nullptr, int nsplit = 1)
 {
     using SA = Stage<AK, BMT, BK>;
     using SB = Stage<BKM, BN, BK>;
@@ -255,11 +255,32 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? (SPH3D_GEMM_DMA != 0 &&
     __shared__ __attribute__((aligned(16))) float lds[LDSF];
     constexpr int TM = WM / 32, TN = WN / 32;    // MFMA tiles per wave
 
+    // XCD-aware workgroup -> tile map (workgroup b runs on XCD b % 8, each XCD has its own L2): the workgroups that read the SAME
+    // operand rows go to the same XCD, back to back.  Products: the tiles_n column tiles of a tile row (they share the A rows;
+    // row-major tile ids put them on tiles_n different XCDs and every XCD fetched the rows from HBM itself).  Weight gradient:
+    // the tiles of one k-split (they share the split's X and dY rows: round-3 counters, 268 MB fetched for 151 MB of operands
+    // at (32768, 1024 -> 128), the kernel within 15 % of the HBM rate).  Ids are dealt in groups of 8 rows (splits) x all their
+    // tiles; the grid is padded to whole groups and the surplus workgroups leave at once.
     const int tiles_n = (N + BN - 1) / BN;
-    const int tile = (int)blockIdx.x;
-    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    const int tiles_m = (M + BMT - 1) / BMT;
+    const int wg = (int)blockIdx.x;
+    int tm, tn, ksplit = 0;
+    if (SPLITK) {
+        const int T = tiles_m * tiles_n;
+        const int g = wg / (8 * T), r = wg - g * 8 * T;
+        ksplit = g * 8 + (r & 7);
+        if (ksplit >= nsplit) return;
+        const int tile = r >> 3;
+        tm = tile / tiles_n;
+        tn = tile - tm * tiles_n;
+    } else {
+        const int g = wg / (8 * tiles_n), r = wg - g * 8 * tiles_n;
+        tm = g * 8 + (r & 7);
+        tn = r >> 3;
+        if (tm >= tiles_m) return;
+    }
     const int m0 = tm * BMT, n0 = tn * BN;
-    const int k_begin = SPLITK ? (int)blockIdx.y * kchunk : 0;
+    const int k_begin = SPLITK ? ksplit * kchunk : 0;
     const int k_end = SPLITK ? ((k_begin + kchunk) < Kd ? (k_begin + kchunk) : Kd) : Kd;
 
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
@@ -396,7 +417,7 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? (SPH3D_GEMM_DMA != 0 &&
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
-    float* Cout = SPLITK ? Cmat + (size_t)blockIdx.y * ((size_t)M * ldc) : Cmat;
+    float* Cout = SPLITK ? Cmat + (size_t)ksplit * ((size_t)M * ldc) : Cmat;
     if (!GUARD) {
         // whole tiles: stage each wave's 32 x WN slab through its own LDS region (the operand buffers are free after the
         // loop's last barrier) and write it back as float4 rows: WN/4 lanes cover one row, 16 B per lane, instead of
@@ -509,6 +530,13 @@ __global__ __launch_bounds__(256) void gemm_reduce_splits(int nsplit, int total,
     }
 }
 
+// padded 1-D grid of the XCD-aware tile map (see the kernel): groups of 8 tile rows (k-splits) x all their tiles
+static unsigned gemm_grid(long long tiles_m, long long tiles_n, long long nsplit = 0)
+{
+    if (nsplit > 0) return (unsigned)(((nsplit + 7) / 8) * 8 * tiles_m * tiles_n);
+    return (unsigned)(((tiles_m + 7) / 8) * 8 * tiles_n);
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 
 template <bool AK, bool BKM, bool GUARD>
@@ -525,17 +553,17 @@ static void launch_gemm_tiles(int M, int N, int Kd, const float* A, int lda, con
         // (6144, 2048 -> 256) ... ) -- with >= 512 big tiles the 128x128 kernel wins since its prefetch registers stopped
         // going through scratch: 0.100 vs 0.106 ms at (131072, 256 -> 128), 0.089 vs 0.098 at (32768, 512 -> 256),
         // 0.062 vs 0.071 at (6144, 256 -> 2048)
-        hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 64, 64, BKS, false, GUARD>), dim3((unsigned)ntiles(64, 64)), dim3(256), 0, st, M,
+        hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 64, 64, BKS, false, GUARD>), dim3(gemm_grid((M + 63) / 64, (N + 63) / 64)), dim3(256), 0, st, M,
                            N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
     } else if (N > 64 && ntiles(128, 128) >= 512) {
         constexpr int BKX = BKS;
-        hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 128, BKX, false, GUARD>), dim3((unsigned)ntiles(128, 128)), dim3(256), 0, st,
+        hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 128, BKX, false, GUARD>), dim3(gemm_grid((M + 127) / 128, (N + 127) / 128)), dim3(256), 0, st,
                            M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
     } else if (N <= 64 && ntiles(128, 64) >= 512) {      // (wider outputs with fewer rows: 64x64, e.g. 0.092 vs 0.111 ms at (32768, 1024 -> 128))
-        hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 64, BKS, false, GUARD>), dim3((unsigned)ntiles(128, 64)), dim3(256), 0, st,
+        hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 64, BKS, false, GUARD>), dim3(gemm_grid((M + 127) / 128, (N + 63) / 64)), dim3(256), 0, st,
                            M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
     } else {
-        hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 64, 64, BKS, false, GUARD>), dim3((unsigned)ntiles(64, 64)), dim3(256), 0, st, M,
+        hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 64, 64, BKS, false, GUARD>), dim3(gemm_grid((M + 63) / 64, (N + 63) / 64)), dim3(256), 0, st, M,
                            N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
     }
 }
@@ -616,7 +644,7 @@ extern "C" int sph3d_pointwise_gemm_bnstats(int R, int Cin, int Cout, const floa
         return SPH3D_EUNSUPPORTED;
     }
     hipStream_t st = as_stream(stream);
-    const unsigned tiles = (unsigned)((R / bm) * (Cout / bn));
+    const unsigned tiles = gemm_grid(R / bm, Cout / bn);
     if (bm == 128 && bn == 128)
         hipLaunchKernelGGL((gemm_f32_mfma<true, false, 128, 128, BKS, false, false, true>), dim3(tiles), dim3(256), 0, st, R, Cout, Cin, X,
                            Cin, W, Cout, Y, Cout, bias, 0, 0, partial);
@@ -652,11 +680,11 @@ extern "C" int sph3d_pointwise_gemm_tn(int R, int Cin, int Cout, const float* X,
     // dW[Cin,Cout] = X^T * dY : A(m=cin, k=r) = X[r*Cin + cin] (row contiguous), B(k=r, n=cout) = dY[r*Cout + cout]
     const bool whole = (Cin % 128 == 0) && (Cout % bn == 0) && (R % kchunk == 0) && aligned16(X) && aligned16(dY) && aligned16(out);
 #define SPH3D_TN(BNN, G)                                                                                                   \
-    hipLaunchKernelGGL((gemm_f32_mfma<false, false, 128, BNN, BKL, true, G>), dim3(tiles, nsplit), dim3(256), 0, st, Cin, Cout, R, X, \
-                       Cin, dY, Cout, out, Cout, nullptr, 0, kchunk)
+    hipLaunchKernelGGL((gemm_f32_mfma<false, false, 128, BNN, BKL, true, G>), dim3(gemm_grid(tiles, 1, nsplit)), dim3(256), 0, st, Cin, Cout, R, X, \
+                       Cin, dY, Cout, out, Cout, nullptr, 0, kchunk, nullptr, nsplit)
 #define SPH3D_TN16(BNN)                                                                                                    \
-    hipLaunchKernelGGL((gemm_f32_mfma<false, false, 128, BNN, BKS, true, false>), dim3(tiles, nsplit), dim3(256), 0, st, Cin, Cout, R, X, \
-                       Cin, dY, Cout, out, Cout, nullptr, 0, kchunk)
+    hipLaunchKernelGGL((gemm_f32_mfma<false, false, 128, BNN, BKS, true, false>), dim3(gemm_grid(tiles, 1, nsplit)), dim3(256), 0, st, Cin, Cout, R, X, \
+                       Cin, dY, Cout, out, Cout, nullptr, 0, kchunk, nullptr, nsplit)
     // whole tiles: BK = 16 at four workgroups per CU (8 + 8 prefetch registers with the 2x4 transposing units): 0.786 vs
     // 0.855 ms over the step's shapes against BK = 32 at two per CU
     if (whole) { if (bn == 128) SPH3D_TN16(128); else SPH3D_TN16(64); }

@@ -45,6 +45,14 @@ for cfg in "nn:KIND=nn SHAPE=131072,256,128" "nt:KIND=nt SHAPE=131072,256,128" "
   bash tools/gpu_pmc3.sh ${TAG}_mfma_$name tools/exp_gemm_pmc.py "$env" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE" gemm | tail -3
 done
 ls $OUT | grep "^$TAG" | head -60
+# HBM traffic of the GEMMs the roofline object may name (separate passes, as for the conv kernels)
+for cfg in "nn:KIND=nn SHAPE=131072,256,128" "tn:KIND=tn SHAPE=32768,1024,128" "tn0:KIND=tn SHAPE=131072,256,128"; do
+  name=${cfg%%:*}; env=${cfg#*:}
+  for pass in "FETCH_SIZE" "WRITE_SIZE"; do
+    n=$(echo $pass | cut -c1-3)
+    bash tools/gpu_pmc3.sh ${TAG}_gemm${name}_$n tools/exp_gemm_pmc.py "$env" "$pass" gemm | tail -3
+  done
+done
 # neighbour search (level-0 plain search, 16 x 8192, K = 64): instruction mix of the in-tree kernel and, when a library built
 # with the previous scan is present (sph3d_gcn_amd/csrc/libsph3d_nnbefore.so), of that one
 for cfg in "after:" "before:SPH3D_LIB=$GRAFT_REPO_ROOT/sph3d_gcn_amd/csrc/libsph3d_nnbefore.so"; do
