@@ -375,8 +375,9 @@ def main():
     opt = torch.optim.Adam([flat.flat_param], lr=1e-3, eps=1e-4, fused=True)
     nparams = flat.flat_param.numel()
 
-    # (launch mode: eager on three HIP streams.  A HIP-graph replay of the step was tried in round 1 and removed in round 2:
-    #  capturing the three-stream step does not complete on this stack — DESIGN.md section 5)
+    # (launch mode: eager on three HIP streams.  A HIP-graph replay of the whole step does capture once every autograd node lives
+    #  on a non-default stream (tools/exp_capture.py, round 3) and buys nothing: the feature path replays in 7.46 ms against 7.46
+    #  eager — the GPU, not the host, is the bound — and the three-branch graph replays serialised, 12.1 against 10.7 ms)
     mode = "eager"
 
     def one_step():

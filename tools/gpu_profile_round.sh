@@ -40,7 +40,7 @@ for cfg in "fwd:MODE=fwd" "bwd:MODE=bwd"; do
   bash tools/gpu_pmc3.sh ${TAG}_sq1_$name tools/exp_conv_pmc.py "$env C=128" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" dwconv | tail -2
   bash tools/gpu_pmc3.sh ${TAG}_sq2_$name tools/exp_conv_pmc.py "$env C=128" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" dwconv | tail -2
 done
-for cfg in "nn:KIND=nn SHAPE=131072,256,128" "nt:KIND=nt SHAPE=131072,256,128" "tn:KIND=tn SHAPE=32768,1024,128"; do
+for cfg in "nn:KIND=nn SHAPE=131072,256,128" "nt:KIND=nt SHAPE=131072,256,128" "tn:KIND=tn SHAPE=32768,1024,128" "tn0:KIND=tn SHAPE=131072,256,128"; do
   name=${cfg%%:*}; env=${cfg#*:}
   bash tools/gpu_pmc3.sh ${TAG}_mfma_$name tools/exp_gemm_pmc.py "$env" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE" gemm | tail -3
 done

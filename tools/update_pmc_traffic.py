@@ -1,0 +1,74 @@
+"""profiles/pmc_traffic.json from the per-pass counter CSVs of tools/gpu_profile_round.sh (copied into profiles/ first).
+usage: python tools/update_pmc_traffic.py [tag]   (tag = r03)
+traffic bytes per launch = FETCH_SIZE[KB] * 2 * 1024 + WRITE_SIZE[KB] * 1024 (the x2 is the gfx950 FETCH_SIZE correction of
+MI355X_MICROARCH.md for 16-B-per-lane reads, which all of these kernels issue)."""
+import csv, json, os, sys
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles") + "/"
+
+
+def avg(path, pat, counter):
+    if not os.path.exists(P + path):
+        return None
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(P + path)) if pat in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    return sum(v) / len(v) if v else None
+
+
+t = json.load(open(P + "pmc_traffic.json"))
+
+
+def traffic(tag, pat, extra=None):
+    f, w = avg("%s_pmc_%s_FET.csv" % (TAG, tag), pat, "FETCH_SIZE"), avg("%s_pmc_%s_WRI.csv" % (TAG, tag), pat, "WRITE_SIZE")
+    if f is None or w is None:
+        return None
+    tot = f * 2 * 1024 + w * 1024
+    if extra:
+        fr, wr = avg("%s_pmc_%s_FET.csv" % (TAG, tag), extra, "FETCH_SIZE") or 0, avg("%s_pmc_%s_WRI.csv" % (TAG, tag), extra, "WRITE_SIZE") or 0
+        tot += fr * 2 * 1024 + wr * 1024
+    return int(tot)
+
+
+for key, tag, pat, extra in (
+        ("sph3d_depthwise_conv3d[16, 8192, 8192, 33, 128, 2, 64]", "fwd", "dwconv_fwd_multi", None),
+        ("sph3d_depthwise_conv3d_grad_t[16, 8192, 8192, 33, 128, 2]", "bwd", "dwconv_bwd_t_vec<2, 4, 17", None),
+        ("sph3d_depthwise_conv3d_tiled[16, 8192, 8192, 33, 128, 2]", "fwdt", "dwconv_tile_fwd_whole", None),
+        ("sph3d_pointwise_gemm[131072, 256, 128, 0, 0]", "gemmnn", "gemm_f32_mfma", None),
+        ("sph3d_pointwise_gemm_bnstats[131072, 256, 128]", "gemmnn", "gemm_f32_mfma", None),
+        ("sph3d_pointwise_gemm_tn[32768, 1024, 128]", "gemmtn", "gemm_f32_mfma", "gemm_reduce_splits"),
+        ("sph3d_pointwise_gemm_tn[131072, 256, 128]", "gemmtn0", "gemm_f32_mfma", "gemm_reduce_splits")):
+    v = traffic(tag, pat, extra)
+    if v is not None:
+        t[key] = v
+
+
+def busy(tag):
+    b = avg("%s_pmc_mfma_%s.csv" % (TAG, tag), "gemm_f32_mfma", "SQ_VALU_MFMA_BUSY_CYCLES")
+    g = avg("%s_pmc_mfma_%s.csv" % (TAG, tag), "gemm_f32_mfma", "GRBM_GUI_ACTIVE")
+    return round(b / (1024 * g / 8), 4) if b and g else None
+
+
+mb = t.setdefault("mfma_pipe_busy", {})
+for key, tag in (("sph3d_pointwise_gemm[131072, 256, 128, 0, 0]", "nn"), ("sph3d_pointwise_gemm_bnstats[131072, 256, 128]", "nn"),
+                 ("sph3d_pointwise_gemm[131072, 128, 256, 0, 1]", "nt"), ("sph3d_pointwise_gemm_tn[32768, 1024, 128]", "tn"),
+                 ("sph3d_pointwise_gemm_tn[131072, 256, 128]", "tn0")):
+    v = busy(tag)
+    if v is not None:
+        mb[key] = v
+
+rows = list(csv.DictReader(open(P + "%s_kernel_trace_by_launch_shape.csv" % TAG)))
+
+
+def tr(pat, col="mean_us", grid=None):
+    for r in rows:
+        if pat in r["kernel"] and (grid is None or r["grid_x"] == str(grid)):
+            return float(r[col])
+
+
+tu = t.setdefault("trace_us", {})
+tu["sph3d_depthwise_conv3d[16, 8192, 8192, 33, 128, 2, 64]"] = tr("dwconv_fwd_multi<2, 32, 4>")
+tu["sph3d_depthwise_conv3d[16, 8192, 8192, 33, 64, 2, 64]"] = tr("dwconv_fwd_multi<2, 16, 4>")
+tu["sph3d_depthwise_conv3d_grad_t[16, 8192, 8192, 33, 64, 2]"] = tr("dwconv_bwd_t_vec<2, 4, 17, true, true>")
+tu["sph3d_depthwise_conv3d_grad_t[16, 8192, 8192, 33, 128, 2]"] = tr("dwconv_bwd_t_vec<2, 4, 17, false, true>", "max_us", 262144)
+json.dump(t, open(P + "pmc_traffic.json", "w"), indent=1)
+print({k: v for k, v in t.items() if not k.startswith("_") and not isinstance(v, dict)})
+print(mb)
