@@ -622,8 +622,13 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
     // workgroup reduction of the per-wave accumulators: waves take turns on one [F][SL] LDS table
     __syncthreads();                 // everyone is done reading lfilt
     float* tab = lds;                // reuse: [F][SL]
-    if (COMPACT) {                   // rows of bins that never occur stay zero
-        for (int e = threadIdx.x; e < F * SL; e += blockDim.x) tab[e] = 0.f;
+    // COMPACT: only the rows of bins that occur are summed, written to the slab and read by reduce_filter_partials (which
+    // writes zeros for the others): half of the slab traffic at S3DIS radii (17 of 33 bins)
+    __shared__ unsigned long long activeMask;
+    if (COMPACT) {
+        if (threadIdx.x == 0) activeMask = 0ull;
+        __syncthreads();
+        if ((int)threadIdx.x < A) atomicOr(&activeMask, 1ull << activeBins[1 + threadIdx.x]);
         __syncthreads();
     }
     for (int w = 0; w < kBwdTWaves; w++) {
@@ -635,7 +640,7 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
 #pragma unroll
                     for (int v = 0; v < V; v++) {
                         float* p = &tab[f * SL + cl0 + v];
-                        *p = (w == 0 && !COMPACT) ? acc[i][v] : (*p + acc[i][v]);
+                        *p = (w == 0) ? acc[i][v] : (*p + acc[i][v]);
                     }
                 }
             }
@@ -643,25 +648,34 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
         __syncthreads();
     }
     float* out = partial + ((size_t)xcd * W + w) * ((size_t)F * CR);
+    const unsigned long long am = COMPACT ? activeMask : ~0ull;
     for (int e = threadIdx.x; e < F * SL; e += blockDim.x) {
         const int f = e / SL;
         const int cl = e - f * SL;
-        out[(size_t)f * CR + slice0 + cl] = tab[e];
+        if (!COMPACT || ((am >> f) & 1ull)) out[(size_t)f * CR + slice0 + cl] = tab[e];
     }
 }
 
 // grad_filter[j] = sum over the B*nblocks partial tables, fixed order -> deterministic given the partials.
 // 1024 threads = 32 outputs x 32 partial-lanes (a one-thread-per-output loop over ~1000 slabs is latency-bound; 8 lanes: 20-30 us).
-__global__ __launch_bounds__(1024) void reduce_filter_partials(int nparts, int total, const float* __restrict__ partial,
+__global__ __launch_bounds__(1024) void reduce_filter_partials(int nparts, int total, int CR, const float* __restrict__ partial,
                                                               float* __restrict__ gradFilter,
                                                               const int* __restrict__ activeBins, int compactMax, int npartsCompact)
 {
-    if (activeBins != nullptr && activeBins[0] <= compactMax) nparts = npartsCompact;   // the compact launch wrote the slabs
+    const bool compact = activeBins != nullptr && activeBins[0] <= compactMax;
+    if (compact) nparts = npartsCompact;   // the compact launch wrote the slabs — only the rows of the bins that occur
     __shared__ float red[32][32];      // 32 outputs x 32 partial-lanes
+    __shared__ unsigned long long activeMask;
+    if (compact) {
+        if (threadIdx.x == 0) activeMask = 0ull;
+        __syncthreads();
+        if ((int)threadIdx.x < activeBins[0]) atomicOr(&activeMask, 1ull << activeBins[1 + threadIdx.x]);
+        __syncthreads();
+    }
     const int cx = (int)threadIdx.x & 31, py = (int)threadIdx.x >> 5;
     const int j = blockIdx.x * 32 + cx;
     float s = 0.f;
-    if (j < total) {
+    if (j < total && (!compact || ((activeMask >> (j / CR)) & 1ull))) {
         // eight slabs per trip, loads issued together (one per trip = up to 32 dependent L2 round trips per launch)
         for (int p0 = py; p0 < nparts; p0 += 256) {
             float v[8];
@@ -957,7 +971,7 @@ static int launch_bwd_t_vec(int B, int N, int M, int F, int C, const int* offset
                        W, parts, nslices, offsets, ent_key, ent_scale, order, ab, kCompactBins, input, filter, grad_output,
                        grad_input, partial);
     const int total = F * CR;
-    hipLaunchKernelGGL(reduce_filter_partials, dim3((total + 31) / 32), dim3(1024), 0, st, 8 * W, total, partial,
+    hipLaunchKernelGGL(reduce_filter_partials, dim3((total + 31) / 32), dim3(1024), 0, st, 8 * W, total, CR, partial,
                        grad_filter, ab, kCompactBins, 8 * Wc);
     return check_launch("sph3d_depthwise_conv3d_grad_t");
 }
