@@ -434,13 +434,13 @@ def main():
     for (name, ints), (ms, cnt) in per.items():
         if name == "sph3d_farthest_point_sample":
             continue
-        f = fam.setdefault(family(name), [0.0, None, (0.0, 0, 0.0)])
+        f = fam.setdefault(family(name), [0.0, None, (0.0, 0, 0, 0.0)])
         f[0] += ms
         # the family's representative call: the one with the most work (FLOPs for the GEMMs, algorithmic bytes otherwise);
         # among equals the weight-gradient product (split-K + slab sum), then the slowest — NOT simply the slowest, which
         # flips between runs when several level-0 products take within a few percent of each other
         work = 2.0 * ints[0] * ints[1] * ints[2] if "gemm" in name else float(algorithmic_bytes(name, ints))
-        call_rank = (work, 1 if name.endswith("_tn") else 0, ms / cnt)
+        call_rank = (work, 1 if name.endswith("_tn") else 0, ints[0], ms / cnt)      # ... then the most rows (level 0), then the slowest
         if call_rank > f[2]:
             f[1], f[2] = (name, ints, ms, cnt), call_rank
     roofline = None

@@ -69,6 +69,22 @@ tu["sph3d_depthwise_conv3d[16, 8192, 8192, 33, 128, 2, 64]"] = tr("dwconv_fwd_mu
 tu["sph3d_depthwise_conv3d[16, 8192, 8192, 33, 64, 2, 64]"] = tr("dwconv_fwd_multi<2, 16, 4>")
 tu["sph3d_depthwise_conv3d_grad_t[16, 8192, 8192, 33, 64, 2]"] = tr("dwconv_bwd_t_vec<2, 4, 17, true, true>")
 tu["sph3d_depthwise_conv3d_grad_t[16, 8192, 8192, 33, 128, 2]"] = tr("dwconv_bwd_t_vec<2, 4, 17, false, true>", "max_us", 262144)
+
+
+def dur_us(path, pat):
+    """mean dispatch duration of a kernel in a counter pass (one row per counter: take one counter's rows)"""
+    if not os.path.exists(P + path):
+        return None
+    v = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(P + path))
+         if pat in r["Kernel_Name"] and r["Counter_Name"] == "SQ_INSTS_MFMA"]
+    return sum(v) / len(v) if v else None
+
+
+for key, tag in (("sph3d_pointwise_gemm_tn[131072, 256, 128]", "tn0"), ("sph3d_pointwise_gemm_tn[32768, 1024, 128]", "tn"),
+                 ("sph3d_pointwise_gemm[131072, 256, 128, 0, 0]", "nn")):
+    a, b = dur_us("%s_pmc_mfma_%s.csv" % (TAG, tag), "gemm_f32_mfma"), dur_us("%s_pmc_mfma_%s.csv" % (TAG, tag), "gemm_reduce_splits")
+    if a is not None:
+        tu[key] = round(a + (b or 0.0), 1)          # product kernel (+ slab sum) in the isolated rocprofv3 pass of that call
 json.dump(t, open(P + "pmc_traffic.json", "w"), indent=1)
 print({k: v for k, v in t.items() if not k.startswith("_") and not isinstance(v, dict)})
 print(mb)
