@@ -54,7 +54,9 @@ for cfg in "nn:KIND=nn SHAPE=131072,256,128" "tn:KIND=tn SHAPE=32768,1024,128" "
   done
 done
 # neighbour search (level-0 plain search, 16 x 8192, K = 64): instruction mix of the in-tree kernel and, when a library built
-# with the previous scan is present (sph3d_gcn_amd/csrc/libsph3d_nnbefore.so), of that one
+# with the previous scan is present (sph3d_gcn_amd/csrc/libsph3d_nnbefore.so), of that one.  To build it: `git show 382d868~1:sph3d_gcn_amd/csrc/nnquery.hip`
+# into a scratch directory next to copies of common.hpp / sphere_bin.hpp, hipcc -c it with the Makefile's flags and link it with the
+# in-tree objects of the other sources (the library is git-ignored and was not kept)
 for cfg in "after:" "before:SPH3D_LIB=$GRAFT_REPO_ROOT/sph3d_gcn_amd/csrc/libsph3d_nnbefore.so"; do
   name=${cfg%%:*}; env=${cfg#*:}
   [ "$name" = "before" ] && [ ! -f $GRAFT_REPO_ROOT/sph3d_gcn_amd/csrc/libsph3d_nnbefore.so ] && continue
