@@ -16,7 +16,7 @@
 
 namespace sph3d {
 
-constexpr int kPtsPerWG = 16;   // 4 waves x 4 points
+constexpr int kPtsPerWG = 16;   // 4 waves x 4 points: the launches with many points; small ones take 4 (pts_per_wg)
 
 enum class Mode { Max, Avg, Weighted };
 
@@ -26,15 +26,15 @@ __global__ __launch_bounds__(256) void gather_fwd(
     int B, int Nin, int Mout, int C, int K, int mblocks,
     const int* __restrict__ nnIndex, const int* __restrict__ nnCount,
     const float* __restrict__ input, const float* __restrict__ weight,
-    float* __restrict__ output, int* __restrict__ maxIndex)
+    float* __restrict__ output, int* __restrict__ maxIndex, int ppwg)
 {
     int b, mb;
     xcd_decode((int)blockIdx.x, B, mblocks, b, mb);
     if (b < 0) return;
     const int wave = uniform((int)threadIdx.x >> 6);
     const int lane = lane_id();
-    const int m_begin = mb * kPtsPerWG;
-    const int m_end = (m_begin + kPtsPerWG) < Mout ? (m_begin + kPtsPerWG) : Mout;
+    const int m_begin = mb * ppwg;
+    const int m_end = (m_begin + ppwg) < Mout ? (m_begin + ppwg) : Mout;
     const float* inb = input + (size_t)b * Nin * C;
 
     for (int m = m_begin + wave; m < m_end; m += 4) {
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void gather_fwd_half(
     int B, int Nin, int Mout, int C, int K, int mblocks,
     const int* __restrict__ nnIndex, const int* __restrict__ nnCount,
     const float* __restrict__ input, const float* __restrict__ weight,
-    float* __restrict__ output, int* __restrict__ maxIndex)
+    float* __restrict__ output, int* __restrict__ maxIndex, int ppwg)
 {
     int b, mb;
     xcd_decode((int)blockIdx.x, B, mblocks, b, mb);
@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256) void gather_fwd_half(
     const int half = lane >> 5;
     const int c = (lane & 31) * 4;
     const bool act = c < C;
-    const int m_begin = mb * kPtsPerWG;
-    const int m_end = (m_begin + kPtsPerWG) < Mout ? (m_begin + kPtsPerWG) : Mout;
+    const int m_begin = mb * ppwg;
+    const int m_end = (m_begin + ppwg) < Mout ? (m_begin + ppwg) : Mout;
     const float* inb = input + (size_t)b * Nin * C + (act ? c : 0);
 
     for (int m = m_begin + wave; m < m_end; m += 4) {
@@ -337,17 +337,22 @@ static int launch_fwd(const char* who, int B, int Nin, int Mout, int C, int K,
     SPH3D_REQUIRE(B >= 0 && Nin > 0 && Mout >= 0 && C > 0 && K > 0, "%s: bad dims B=%d N=%d M=%d C=%d K=%d",
                   who, B, Nin, Mout, C, K);
     if (B == 0 || Mout == 0) return SPH3D_OK;
-    const int mblocks = (Mout + kPtsPerWG - 1) / kPtsPerWG;
+    // Output points per workgroup: these kernels have no per-workgroup prologue, so the small levels (a few thousand output
+    // points) take ONE point per wave — four per wave left them with 2-8 waves per SIMD walking 4 x ~50 dependent gathers each
+    // (round 3, tools/exp_calls.py: max pooling 36 -> 17 us at 16 x 128 points of 512 channels, 80 -> 64 us at level 0);
+    // launches of >= 65536 points keep four per wave (mean interpolation at level 0: 80 vs 82 us).
+    const int ppwg = (long long)B * Mout >= 65536 ? kPtsPerWG : 4;
+    const int mblocks = (Mout + ppwg - 1) / ppwg;
     const dim3 grid(xcd_grid(B, mblocks));
     if (C % 4 == 0 && C <= 128)
         hipLaunchKernelGGL((gather_fwd_half<MODE>), grid, dim3(256), 0, st, B, Nin, Mout, C, K, mblocks,
-                           nn_index, nn_count, input, weight, output, max_index);
+                           nn_index, nn_count, input, weight, output, max_index, ppwg);
     else if (C % 4 == 0)
         hipLaunchKernelGGL((gather_fwd<MODE, 4>), grid, dim3(256), 0, st, B, Nin, Mout, C, K, mblocks,
-                           nn_index, nn_count, input, weight, output, max_index);
+                           nn_index, nn_count, input, weight, output, max_index, ppwg);
     else
         hipLaunchKernelGGL((gather_fwd<MODE, 1>), grid, dim3(256), 0, st, B, Nin, Mout, C, K, mblocks,
-                           nn_index, nn_count, input, weight, output, max_index);
+                           nn_index, nn_count, input, weight, output, max_index, ppwg);
     return check_launch(who);
 }
 
