@@ -13,7 +13,7 @@ import torch
 from . import _lib
 
 BALANCE_MIN_POINTS = 1024   # binned graphs with at least this many source points get a degree-balanced gradient order
-_MAX_ENTRIES = 16      # one S3DIS step builds 12 (8 binned intra graphs + 4 inter graphs); entries pin ~150 MB each at level 0
+_MAX_ENTRIES = 24      # one S3DIS step builds 16 (8 binned intra graphs, 4 un-pooling and 4 pooling graphs); entries pin ~150 MB each at level 0
 _cache = collections.OrderedDict()
 
 
@@ -48,6 +48,12 @@ def source_order(nn_index):
             order.record_stream(torch.cuda.current_stream())
             hit[2].add(cur)
     return order
+
+
+def peek(nn_index, nn_count, n_src):
+    """the cached transpose of an un-binned, un-weighted graph, or None (never builds: for gradients that have a fallback)"""
+    key = (_ident(nn_index), _ident(nn_count), _ident(None), _ident(None), int(n_src), 1, tuple(nn_index.shape))
+    return transpose(nn_index, nn_count, n_src) if key in _cache else None
 
 
 def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1, counted_workspace=None):

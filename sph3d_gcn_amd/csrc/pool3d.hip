@@ -253,6 +253,70 @@ __global__ __launch_bounds__(256) void maxpool_bwd(
     }
 }
 
+// max-pool gradient as a GATHER over the transposed pooling graph (round 3): source point n walks its in-edges m and takes
+// gradOutput[b,m,c] where maxIndex[b,m,c] == n.  Every gradInput element is written exactly once: no memset, no float
+// atomics (the scatter above: 4.2 M single-lane atomics at S3DIS level 0, 151 us; 47-83 us on the small levels), and the sum
+// of the (few) terms of an element has a fixed order.  Rows m WITHOUT neighbours keep maxIndex 0 in the forward pass and the
+// scatter adds their gradient to point 0; they have no edge here, so the wave of point 0 looks for them in nn_count.
+template <int V>
+__global__ __launch_bounds__(256) void maxpool_bwd_t(
+    int B, int Nin, int Mout, int C, int nblocks, int ppwg,
+    const int* __restrict__ offsets, const int* __restrict__ entKey, const int* __restrict__ nnCount,
+    const int* __restrict__ maxIndex, const float* __restrict__ gradOutput, float* __restrict__ gradInput)
+{
+    int b, nb;
+    xcd_decode((int)blockIdx.x, B, nblocks, b, nb);
+    if (b < 0) return;
+    const int wave = uniform((int)threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int n_begin = nb * ppwg;
+    const int n_end = (n_begin + ppwg) < Nin ? (n_begin + ppwg) : Nin;
+    const float* gob = gradOutput + (size_t)b * Mout * C;
+    const int* mib = maxIndex + (size_t)b * Mout * C;
+    const int* __restrict__ offb = offsets + (size_t)b * (Nin + 1);
+    for (int n = n_begin + wave; n < n_end; n += 4) {
+        const int e0 = offb[n], e1 = offb[n + 1];
+        for (int c0 = 0; c0 < C; c0 += 64 * V) {
+            const int c = c0 + lane * V;
+            const bool act = c < C;
+            const int cc = act ? c : 0;
+            float acc[V];
+#pragma unroll
+            for (int v = 0; v < V; v++) acc[v] = 0.f;
+            auto take = [&](int m) {       // branch-free: inactive lanes read channel 0
+                if (V == 4) {
+                    const int4 a = *reinterpret_cast<const int4*>(&mib[(size_t)m * C + cc]);
+                    const float4 g = *reinterpret_cast<const float4*>(&gob[(size_t)m * C + cc]);
+                    acc[0] += a.x == n ? g.x : 0.f;
+                    acc[1 % V] += a.y == n ? g.y : 0.f;
+                    acc[2 % V] += a.z == n ? g.z : 0.f;
+                    acc[3 % V] += a.w == n ? g.w : 0.f;
+                } else {
+                    acc[0] += mib[(size_t)m * C + cc] == n ? gob[(size_t)m * C + cc] : 0.f;
+                }
+            };
+#pragma unroll 4
+            for (int e = e0; e < e1; e++) take(entKey[e]);
+            if (n == 0) {                  // rows without neighbours: maxIndex 0 (see above); 64 rows per trip
+                for (int m0 = 0; m0 < Mout; m0 += 64) {
+                    const int mm = m0 + lane;
+                    const int cnt = mm < Mout ? nnCount[(size_t)b * Mout + mm] : 1;
+                    unsigned long long empty = __ballot(cnt == 0);
+                    while (empty != 0ull) {
+                        const int bit = (int)__builtin_ctzll(empty);
+                        empty &= empty - 1ull;
+                        take(m0 + bit);
+                    }
+                }
+            }
+            if (act) {
+#pragma unroll
+                for (int v = 0; v < V; v++) gradInput[((size_t)b * Nin + n) * C + c + v] = acc[v];
+            }
+        }
+    }
+}
+
 // Few sources with many in-edges each (un-pooling: 2048 coarse points collect ~100 fine points each): one WORKGROUP per
 // source, its four waves take every fourth in-edge and the partial sums meet in LDS.  One wave per source (gather_bwd_t)
 // leaves such a launch with eight waves per SIMD in total and a 100-edge dependent chain per wave: 0.13 ms at the decoder's
@@ -411,6 +475,24 @@ extern "C" int sph3d_max_pool3d_grad(int B, int N, int M, int C, const int* max_
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(maxpool_bwd, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, st, B, N, M, C, max_index, grad_output, grad_input);
     return check_launch("sph3d_max_pool3d_grad");
+}
+
+extern "C" int sph3d_max_pool3d_grad_t(int B, int N, int M, int C, const int* offsets, const int* ent_key, const int* nn_count,
+                                       const int* max_index, const float* grad_output, float* grad_input, sph3d_stream_t stream)
+{
+    SPH3D_REQUIRE(B >= 0 && N > 0 && M >= 0 && C > 0, "MaxPool3dGrad: bad dims B=%d N=%d M=%d C=%d", B, N, M, C);
+    if (B == 0) return SPH3D_OK;
+    hipStream_t st = as_stream(stream);
+    const int ppwg = (long long)B * N >= 65536 ? kPtsPerWG : 4;
+    const int nblocks = (N + ppwg - 1) / ppwg;
+    const dim3 grid(xcd_grid(B, nblocks));
+    if (C % 4 == 0)
+        hipLaunchKernelGGL(maxpool_bwd_t<4>, grid, dim3(256), 0, st, B, N, M, C, nblocks, ppwg, offsets, ent_key, nn_count, max_index,
+                           grad_output, grad_input);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_t<1>, grid, dim3(256), 0, st, B, N, M, C, nblocks, ppwg, offsets, ent_key, nn_count, max_index,
+                           grad_output, grad_input);
+    return check_launch("sph3d_max_pool3d_grad_t");
 }
 
 extern "C" int sph3d_avg_pool3d(int B, int N, int M, int C, int K, const int* nn_index, const int* nn_count,

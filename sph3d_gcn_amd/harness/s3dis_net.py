@@ -175,6 +175,11 @@ class GraphPlan:
     def _make_pool(self, l, g):
         g["inter_idx"] = s3g_util.gather_nd(g["intra_idx"], self.indices[l])       # models/SPH3D_s3dis.py:68-72
         g["inter_cnt"] = s3g_util.gather_nd(g["intra_cnt"], self.indices[l])
+        if self.config.pool_method == 'max' and g["inter_idx"].is_cuda:
+            # the max-pool gradient gathers over the transposed pooling graph when one exists (tf_pool3d): built here, off the
+            # critical path, like the transposes of the convolution graphs
+            from .. import _tgraph
+            _tgraph.transpose(g["inter_idx"], g["inter_cnt"], self.xyz_layers[l].shape[1])
 
     def _make_dec(self, l):
         c = self.config

@@ -126,17 +126,36 @@ def _avg_backward(ctx, grad_output):
 _avg_pool3d.register_autograd(_avg_backward, setup_context=_avg_setup)
 
 
+def _max_pool3d_grad_t_impl(input, grad_output, max_index, nn_count, tg):
+    """the gradient as a gather over the transposed pooling graph tg = (offsets, ent_key, ...) (sph3d_max_pool3d_grad_t)"""
+    grad_output, max_index = _lib.f32(grad_output), _lib.i32(max_index)
+    B, N, C = input.shape
+    M = grad_output.shape[1]
+    grad_input = torch.empty((B, N, C), dtype=torch.float32, device=input.device)
+    _lib.check(_lib.lib().sph3d_max_pool3d_grad_t(B, N, M, C, _lib.ptr(tg[0]), _lib.ptr(tg[1]), _lib.ptr(nn_count),
+                                                  _lib.ptr(max_index), _lib.ptr(grad_output), _lib.ptr(grad_input),
+                                                  _lib.stream_ptr()))
+    return grad_input
+
+
 class _MaxPool3dFn(torch.autograd.Function):      # eager fast path (see tf_conv3d._DepthwiseConv3dFn)
     @staticmethod
     def forward(ctx, input, nn_index, nn_count):
         output, max_index = _max_pool3d_impl(input, nn_index, nn_count)
-        ctx.save_for_backward(input, max_index)
+        ctx.save_for_backward(input, max_index, nn_index, nn_count)
         ctx.mark_non_differentiable(max_index)
         return output, max_index
 
     @staticmethod
     def backward(ctx, grad_output, grad_index):
-        input, max_index = ctx.saved_tensors
+        input, max_index, nn_index, nn_count = ctx.saved_tensors
+        # a transposed pooling graph someone built ahead of time (the harness does, on its graph stream): gather, no atomics;
+        # otherwise the reference's scatter (building the transpose here would cost more than it saves)
+        tg = None
+        if input.is_cuda and nn_index.dtype == torch.int32 and nn_count.dtype == torch.int32:
+            tg = _tgraph.peek(nn_index, nn_count, input.shape[1])
+        if tg is not None:
+            return _max_pool3d_grad_t_impl(input, grad_output, max_index, nn_count, tg), None, None
         return _max_pool3d_grad_impl(input, grad_output, max_index), None, None
 
 

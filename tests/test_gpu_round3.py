@@ -467,3 +467,45 @@ def test_separable_layer_inference_fused_equals_layer_by_layer(dev, with_bn):
     assert (n_f, n_u) == (1, 0)
     assert names_f == names_u
     np.testing.assert_allclose(_n(out_f), _n(out_u), rtol=2e-5, atol=2e-5)
+
+
+# ---- max-pool gradient as a gather over the transposed pooling graph (sph3d_max_pool3d_grad_t) ---------------------------
+@pytest.mark.parametrize("case", [(2, 600, 150, 64, 24), (3, 1024, 1024, 128, 32), (16, 384, 128, 512, 64), (1, 200, 77, 35, 16)],
+                         ids=lambda c: "B%d-N%d-M%d-C%d-K%d" % c)
+def test_max_pool_gradient_gather_form_equals_scatter_form_and_oracle(dev, case):
+    from sph3d_gcn_amd import tf_pool3d, _lib
+    B, N, M, C, K = case
+    xyz = synth.uniform_cloud(9, B, N, 1.0)
+    xt = _t(xyz, dev)
+    q = xt[:, :M].contiguous()
+    idx, cnt, dst = tf_nnquery.build_sphere_neighbor(xt, q, 0.2, None, K)
+    cnt = cnt.clone()
+    cnt[:, 3] = 0                                   # a row without neighbours: its gradient goes to point 0 (max_index 0)
+    if M > 10:
+        cnt[0, 10] = 0
+    rng = np.random.RandomState(C)
+    x = rng.randn(B, N, C).astype(np.float32)
+    x[:, :, 0] = np.round(x[:, :, 0])               # ties in one channel: first maximum wins in both forms
+    go = rng.randn(B, M, C).astype(np.float32)
+
+    def run(with_transpose):
+        _tgraph.clear()
+        if with_transpose:
+            _tgraph.transpose(idx, cnt, N)
+        xin = _t(x, dev).requires_grad_(True)
+        out, mi = tf_pool3d.max_pool3d(xin, idx, cnt)
+        _lib.timing_start()
+        try:
+            out.backward(_t(go, dev))
+        finally:
+            names = [c[0] for c in _lib.timing_stop()]
+        return _n(xin.grad), _n(mi), names
+
+    g_t, mi_t, names_t = run(True)
+    g_s, mi_s, names_s = run(False)
+    assert "sph3d_max_pool3d_grad_t" in names_t and "sph3d_max_pool3d_grad" in names_s and "sph3d_max_pool3d_grad_t" not in names_s
+    np.testing.assert_array_equal(mi_t, mi_s)
+    np.testing.assert_allclose(g_t, g_s, **TOL)         # sums of a few terms in a different order (the scatter's order is arbitrary)
+    g_o = oracle.max_pool3d_grad(x, go, mi_s)
+    np.testing.assert_allclose(g_t, g_o, **TOL)
+    assert np.abs(g_t[:, 0]).sum() > 0              # the empty rows' gradients did reach point 0
