@@ -509,3 +509,56 @@ def test_max_pool_gradient_gather_form_equals_scatter_form_and_oracle(dev, case)
     g_o = oracle.max_pool3d_grad(x, go, mi_s)
     np.testing.assert_allclose(g_t, g_o, **TOL)
     assert np.abs(g_t[:, 0]).sum() > 0              # the empty rows' gradients did reach point 0
+
+
+# ---- seeded random shapes: the new neighbour-search scan and the fused inference layer against the oracle ------------------
+@pytest.mark.parametrize("seed", range(12))
+def test_neighbor_search_random_shapes_vs_oracle(dev, seed):
+    """bit-exact ids / counts / distances for random (B, N, M, K, radius) incl. ragged N (sentinel padding of the LDS image), inter
+    graphs, clouds with duplicated points and queries that need growth passes; odd seeds run the fixed-radius mode"""
+    rng = np.random.RandomState(1000 + seed)
+    B = int(rng.randint(1, 6))
+    N = int(rng.choice([17, 63, 64, 65, 127, 129, 500, 1000, 2049, 4100]))
+    M = N if rng.rand() < 0.5 else int(rng.randint(1, 3000))
+    K = int(rng.choice([1, 3, 8, 16, 33, 64, 100]))
+    radius = float(rng.choice([0.02, 0.05, 0.1, 0.25, 0.6]))
+    db = rng.rand(B, N, 3).astype(np.float32)
+    if N > 20:
+        db[:, 5] = db[:, 4]                                   # duplicated points: equal distances, ascending index wins
+    q = db if M == N else rng.rand(B, M, 3).astype(np.float32)
+    fixed = bool(seed & 1)
+    i_o, c_o, d_o = oracle.build_sphere_neighbor(db, q, radius, None, K, fixed=fixed)
+    tf_nnquery.set_radius_mode("fixed" if fixed else "compat")
+    try:
+        idx, cnt, dst = tf_nnquery.build_sphere_neighbor(_t(db, dev), _t(q, dev), radius, None, K)
+    finally:
+        tf_nnquery.set_radius_mode("compat")
+    np.testing.assert_array_equal(_n(cnt), c_o)
+    np.testing.assert_array_equal(_n(idx), i_o)
+    np.testing.assert_array_equal(_n(dst).view(np.int32), d_o.view(np.int32))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fused_inference_separable_conv_random_shapes(dev, seed):
+    rng = np.random.RandomState(77 + seed)
+    B = int(rng.randint(1, 10))
+    N = int(rng.randint(40, 900))
+    C = int(rng.choice([4, 12, 32, 64, 100, 128]))
+    r = int(rng.choice([1, 2]))
+    Cout = int(rng.choice([16, 48, 64, 128]))
+    K = int(rng.choice([8, 24, 64]))
+    kernel = [int(rng.choice([4, 8])), 2, int(rng.choice([1, 2, 3]))]
+    F = kernel[0] * kernel[1] * kernel[2] + 1
+    xyz = _t(rng.rand(B, N, 3).astype(np.float32), dev)
+    idx, cnt, dst = tf_nnquery.build_sphere_neighbor(xyz, xyz, 0.2, None, K)
+    filt = tf_buildkernel.spherical_kernel(xyz, xyz, idx, cnt, dst, 0.2, kernel)
+    x = rng.randn(B, N, C).astype(np.float32)
+    dw = rng.randn(F, C, r).astype(np.float32)
+    w = (rng.randn(C * r, Cout) / np.sqrt(C * r)).astype(np.float32)
+    bias = rng.randn(Cout).astype(np.float32)
+    out = tf_conv3d.separable_conv3d_fused(_t(x, dev), _t(dw, dev), _t(w, dev), idx, cnt, filt, bias=_t(bias, dev), elu=True)
+    d = oracle.depthwise_conv3d(x, dw, _n(idx), _n(cnt), _n(filt)).astype(np.float64).reshape(-1, C * r)
+    y = d @ w.astype(np.float64) + bias
+    want = np.where(y > 0, y, np.expm1(np.minimum(y, 0))).reshape(B, N, Cout)
+    mag = max(1.0, float(np.abs(want).max()))
+    np.testing.assert_allclose(_n(out) / mag, want / mag, rtol=2e-5, atol=2e-5)
