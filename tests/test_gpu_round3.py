@@ -562,3 +562,26 @@ def test_fused_inference_separable_conv_random_shapes(dev, seed):
     want = np.where(y > 0, y, np.expm1(np.minimum(y, 0))).reshape(B, N, Cout)
     mag = max(1.0, float(np.abs(want).max()))
     np.testing.assert_allclose(_n(out) / mag, want / mag, rtol=2e-5, atol=2e-5)
+
+
+# (R, Cin, Cout): every tile class of the LDS-DMA kernels (128x128 / 128x64 / 64x64), tile-row counts that are not multiples of 8
+# (padded XCD-aware grids), one and several column tiles, k loops of one and many tiles
+GEMM_DMA_SHAPES = [(65536, 128, 128), (65536, 32, 64), (2048, 256, 256), (128 * 13, 64, 128), (128 * 21, 16, 512), (128 * 3, 1024, 64),
+                   (66048, 48, 128), (128 * 515, 80, 64)]
+
+
+@pytest.mark.parametrize("shape", GEMM_DMA_SHAPES, ids=lambda s: "R%d-K%d-N%d" % s)
+def test_gemm_lds_dma_kernels_all_three_products(dev, shape):
+    from sph3d_gcn_amd import tf_gemm
+    R, Ci, Co = shape
+    g = torch.Generator(device="cpu").manual_seed(R + Ci + Co)
+    x = torch.randn(R, Ci, generator=g).to(dev)
+    w = torch.randn(Ci, Co, generator=g).to(dev)
+    dy = torch.randn(R, Co, generator=g).to(dev)
+    y = tf_gemm._pointwise_gemm_impl(x, w, False)
+    dx = tf_gemm._pointwise_gemm_impl(dy, w, True)
+    dw = tf_gemm._pointwise_gemm_tn_impl(x, dy)
+    xd, wd, dyd = x.double(), w.double(), dy.double()
+    for name, got, want in (("nn", y, xd @ wd), ("nt", dx, dyd @ wd.t()), ("tn", dw, xd.t() @ dyd)):
+        scale = float(want.abs().max())
+        np.testing.assert_allclose(_n(got) / scale, _n(want.float()) / scale, rtol=2e-5, atol=2e-5, err_msg=name)
