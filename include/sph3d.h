@@ -361,6 +361,22 @@ int sph3d_separable_conv3d_fused(int B, int N, int M, int F, int C, int r, int K
                                  const float* depthwise_filter, const float* pointwise_weights, const float* bias,
                                  const float* scale, const float* shift, float* output, sph3d_stream_t stream);
 
+/* ---- the 1x1 layer with few outputs over two operand halves (the logits layer) ------------------------------------------------
+ * tf.concat((unpooled, skip), axis=2) followed by pointwise_conv3d to num_cls outputs (models/SPH3D_s3dis.py:104-108,
+ * utils/sph3gcn_util.py:166-222) without materialising the concatenation:
+ *   sph3d_pointwise_gemm_skinny     Y[R,N] = A1[R,K1] W[0:K1] + A2[R,K2] W[K1:K1+K2] (+ bias[N] or NULL); A2 = NULL with K2 = 0: one operand
+ *   sph3d_pointwise_gemm_skinny_tn  dW[K1+K2,N] = [A1 | A2]^T dY   (workspace: ..._tn_workspace bytes; fixed summation order)
+ * N <= 16, K1 and K2 multiples of 16, K1 + K2 <= 256 in at most four started groups of 64 channels (ceil(K1/64) + ceil(K2/64) <= 4),
+ * 16-byte aligned operands (..._supported() -> 1 | 0; SPH3D_EUNSUPPORTED
+ * otherwise: concatenate and call sph3d_pointwise_gemm / _tn).  The input gradients are sph3d_pointwise_gemm(trans_w = 1) with
+ * the matching rows of W, once per operand half. */
+int sph3d_pointwise_gemm_skinny_supported(int R, int K1, int K2, int N);
+int sph3d_pointwise_gemm_skinny(int R, int K1, int K2, int N, const float* A1, const float* A2, const float* W, const float* bias,
+                                float* Y, sph3d_stream_t stream);
+size_t sph3d_pointwise_gemm_skinny_tn_workspace(int R, int K1, int K2, int N);
+int sph3d_pointwise_gemm_skinny_tn(int R, int K1, int K2, int N, const float* A1, const float* A2, const float* dY, float* dW,
+                                   void* workspace, size_t workspace_bytes, sph3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,10 @@ SIGNATURES = {
     "sph3d_elu_bn_workspace": (_S, [_I] * 2),
     "sph3d_pointwise_gemm_bnstats_blocks": (_I, [_I] * 3),
     "sph3d_pointwise_gemm_bnstats": (_I, [_I] * 3 + [_P] * 6),
+    "sph3d_pointwise_gemm_skinny_supported": (_I, [_I] * 4),
+    "sph3d_pointwise_gemm_skinny": (_I, [_I] * 4 + [_P] * 6),
+    "sph3d_pointwise_gemm_skinny_tn_workspace": (_S, [_I] * 4),
+    "sph3d_pointwise_gemm_skinny_tn": (_I, [_I] * 4 + [_P] * 5 + [_S, _P]),
     "sph3d_separable_conv3d_fused_supported": (_I, [_I] * 6),
     "sph3d_separable_conv3d_fused": (_I, [_I] * 9 + [_P] * 11),
     "sph3d_elu_bn_forward_partials": (_I, [_I] * 3 + [_P] * 6 + [_F, _F] + [_P] * 4),

@@ -323,11 +323,26 @@ def get_model(points, is_training, config=None, graphs=None, points_ready=None):
                                       with_bias=config.with_bias, is_training=is_training)
         net = s3g_util.unpool3d(net, g["inter_idx"], g["inter_cnt"], g["inter_dst"], method=config.unpool_method,
                                 scope='unpool' + str(l + 1))
-        net = torch.cat((net, encoder[l]), dim=2)
-    end_points['feats'] = net
-    net = s3g_util.pointwise_conv3d(net, config.num_cls, scope='logits', with_bn=False,
-                                    with_bias=config.with_bias, activation_fn=None, is_training=is_training)
+        if l + 1 < len(channels):
+            net = torch.cat((net, encoder[l]), dim=2)
+    # the last concatenation (models/SPH3D_s3dis.py:104) feeds only the logits layer: that layer reads its two halves in place
+    # (s3g_util.pointwise_conv3d_concat); end_points['feats'] materialises the concatenation when somebody asks for it
+    end_points = _EndPoints(end_points)
+    end_points.feats_parts = (net, encoder[len(channels) - 1])
+    net = s3g_util.pointwise_conv3d_concat(net, encoder[len(channels) - 1], config.num_cls, scope='logits', with_bn=False,
+                                           with_bias=config.with_bias, activation_fn=None, is_training=is_training)
     return net, end_points
+
+
+class _EndPoints(dict):
+    """end_points whose 'feats' entry (the concatenated decoder output) is built on first access"""
+    feats_parts = None
+
+    def __missing__(self, key):
+        if key == 'feats' and self.feats_parts is not None:
+            self['feats'] = torch.cat(self.feats_parts, dim=2)
+            return self['feats']
+        raise KeyError(key)
 
 
 def get_loss(pred, label, end_points, inner_label):

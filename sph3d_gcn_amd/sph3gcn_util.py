@@ -330,6 +330,24 @@ def pointwise_conv3d(inputs,
                       activation_fn, with_bn, with_bias, reuse, is_training)
 
 
+def pointwise_conv3d_concat(inputs_a, inputs_b, num_out_channels, scope, use_xavier=True, stddev=1e-3, weight_decay=None,
+                            activation_fn=elu, with_bn=False, with_bias=False, reuse=None, is_training=None):
+    """pointwise_conv3d(tf.concat((inputs_a, inputs_b), axis=2), ...) — same variables, same result — without the concatenation
+    when the layer is a plain product with few outputs (the logits layer of models/SPH3D_s3dis.py:104-108: 256 -> num_cls):
+    tf_gemm.linear_concat2 reads the two halves where they are."""
+    ca, cb = inputs_a.shape[-1], inputs_b.shape[-1]
+    if (FUSE_LOGITS_CONCAT and inputs_a.is_cuda and not with_bn and activation_fn is None
+            and tf_gemm.skinny_supported(inputs_a.shape[0] * inputs_a.shape[1], ca, cb, num_out_channels)):
+        kernel = _variable_with_weight_decay(scope + '/weights', shape=[ca + cb, num_out_channels],
+                                             use_xavier=use_xavier, stddev=stddev, with_decay=weight_decay)
+        biases = get_variable_store().get_variable(scope + '/biases', [num_out_channels], _constant(0.0)) if with_bias else None
+        out = tf_gemm.linear_concat2(inputs_a.reshape(-1, ca), inputs_b.reshape(-1, cb), kernel, biases)
+        return out.reshape(inputs_a.shape[0], -1, num_out_channels)
+    return pointwise_conv3d(torch.cat((inputs_a, inputs_b), dim=2), num_out_channels, scope, use_xavier=use_xavier, stddev=stddev,
+                            weight_decay=weight_decay, activation_fn=activation_fn, with_bn=with_bn, with_bias=with_bias,
+                            reuse=reuse, is_training=is_training)
+
+
 def fully_connected(inputs,
                     num_out_channels,
                     scope,
@@ -376,6 +394,7 @@ def unpool3d(inputs, nn_index, nn_count, nn_dist, scope, method):
 
 
 FUSE_GEMM_BN = True    # the statistics of that tail from the GEMM's epilogue where the shape allows (tf_norm.gemm_elu_batch_norm)
+FUSE_LOGITS_CONCAT = True         # pointwise_conv3d_concat: few-output layer over two operand halves (tf_gemm.linear_concat2)
 FUSE_SEPARABLE_INFERENCE = True   # is_training=False under torch.no_grad(): separable_conv3d as ONE kernel (tf_conv3d.separable_conv3d_fused)
 FUSE_ELU_BN = True     # fused sph3d::elu_bn for the ELU -> BN tail (same variables / moving statistics as the unfused ops)
 

@@ -133,3 +133,84 @@ class _GemmBiasActFn(torch.autograd.Function):
 def matmul_bias_act(x, w, bias, elu=False):
     """elu?(x @ w + bias) with the bias and the activation in the GEMM's epilogue"""
     return _GemmBiasActFn.apply(x, w, bias, 1 if elu else 0)
+
+
+# ---- the 1x1 layer with few outputs over two operand halves: the logits layer without its concatenation (csrc/skinny.hip) ----
+def skinny_supported(R, K1, K2, N):
+    return bool(_lib.lib().sph3d_pointwise_gemm_skinny_supported(int(R), int(K1), int(K2), int(N)))
+
+
+def _skinny_impl(a1: torch.Tensor, a2: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """a1[R,K1] @ w[:K1] + a2[R,K2] @ w[K1:] + bias -> [R,N]   (a2 / bias with zero elements: absent)"""
+    _lib.require_device(a1, w)
+    a1, w = _lib.f32(a1), _lib.f32(w)
+    a2 = None if a2 is None or a2.numel() == 0 else _lib.f32(a2)
+    bias = None if bias is None or bias.numel() == 0 else _lib.f32(bias)
+    R, K1 = a1.shape
+    K2 = 0 if a2 is None else a2.shape[1]
+    N = w.shape[1]
+    if w.shape[0] != K1 + K2:
+        raise ValueError("weights should be [K1 + K2, N]")
+    y = torch.empty((R, N), dtype=torch.float32, device=a1.device)
+    _lib.check(_lib.lib().sph3d_pointwise_gemm_skinny(R, K1, K2, N, _lib.ptr(a1), _lib.ptr(a2), _lib.ptr(w), _lib.ptr(bias),
+                                                      _lib.ptr(y), _lib.stream_ptr()))
+    return y
+
+
+def _skinny_tn_impl(a1: torch.Tensor, a2: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """[a1 | a2]^T @ dy -> [K1 + K2, N]"""
+    _lib.require_device(a1, dy)
+    a1, dy = _lib.f32(a1), _lib.f32(dy)
+    a2 = None if a2 is None or a2.numel() == 0 else _lib.f32(a2)
+    R, K1 = a1.shape
+    K2 = 0 if a2 is None else a2.shape[1]
+    N = dy.shape[1]
+    l = _lib.lib()
+    wsb = l.sph3d_pointwise_gemm_skinny_tn_workspace(R, K1, K2, N)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=a1.device)
+    dw = torch.empty((K1 + K2, N), dtype=torch.float32, device=a1.device)
+    _lib.check(l.sph3d_pointwise_gemm_skinny_tn(R, K1, K2, N, _lib.ptr(a1), _lib.ptr(a2), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(ws), wsb,
+                                                _lib.stream_ptr()))
+    return dw
+
+
+_skinny = torch.library.custom_op("sph3d::pointwise_gemm_skinny", mutates_args=())(_skinny_impl)
+
+
+@_skinny.register_fake
+def _(a1, a2, w, bias):
+    return a1.new_empty((a1.shape[0], w.shape[1]))
+
+
+_skinny_tn = torch.library.custom_op("sph3d::pointwise_gemm_skinny_tn", mutates_args=())(_skinny_tn_impl)
+
+
+@_skinny_tn.register_fake
+def _(a1, a2, dy):
+    return a1.new_empty((a1.shape[1] + a2.shape[1], dy.shape[1]))
+
+
+class _SkinnyLinear2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a1, a2, w, bias):
+        ctx.save_for_backward(a1, a2, w)
+        ctx.has_bias = bias is not None
+        return _skinny_impl(a1, a2, w, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a1, a2, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        K1 = a1.shape[1]
+        # the input gradients: the general product with the matching rows of w, one call per half (they are written where autograd
+        # wants them: no slices of a concatenated gradient to copy)
+        da1 = _pointwise_gemm_impl(dy, w[:K1], True) if ctx.needs_input_grad[0] else None
+        da2 = _pointwise_gemm_impl(dy, w[K1:], True) if (a2 is not None and ctx.needs_input_grad[1]) else None
+        dw = _skinny_tn_impl(a1, a2, dy) if ctx.needs_input_grad[2] else None
+        db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
+        return da1, da2, dw, db
+
+
+def linear_concat2(a1, a2, w, bias=None):
+    """[a1 | a2] @ w + bias for few output columns (N <= 16), the concatenation never materialised; a2 may be None"""
+    return _SkinnyLinear2Fn.apply(a1, a2, w, bias)

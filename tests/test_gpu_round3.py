@@ -585,3 +585,76 @@ def test_gemm_lds_dma_kernels_all_three_products(dev, shape):
     for name, got, want in (("nn", y, xd @ wd), ("nt", dx, dyd @ wd.t()), ("tn", dw, xd.t() @ dyd)):
         scale = float(want.abs().max())
         np.testing.assert_allclose(_n(got) / scale, _n(want.float()) / scale, rtol=2e-5, atol=2e-5, err_msg=name)
+
+
+# ---- the few-output 1x1 layer over two operand halves (csrc/skinny.hip) --------------------------------------------------------
+@pytest.mark.parametrize("shape", [(131072, 128, 128, 13), (4096, 64, 0, 16), (1000, 16, 48, 1), (77, 128, 64, 5), (16 * 513 + 3, 112, 128, 13)],
+                         ids=lambda s: "R%d-K%d+%d-N%d" % s)
+def test_skinny_layer_forward_and_gradients(dev, shape):
+    from sph3d_gcn_amd import tf_gemm
+    R, K1, K2, N = shape
+    g = torch.Generator(device="cpu").manual_seed(R + K1)
+    a1 = torch.randn(R, K1, generator=g).to(dev).requires_grad_(True)
+    a2 = torch.randn(R, K2, generator=g).to(dev).requires_grad_(True) if K2 else None
+    w = (torch.randn(K1 + K2, N, generator=g) / (K1 + K2) ** 0.5).to(dev).requires_grad_(True)
+    bias = torch.randn(N, generator=g).to(dev).requires_grad_(True)
+    dy = torch.randn(R, N, generator=g).to(dev)
+    assert tf_gemm.skinny_supported(R, K1, K2, N)
+    y = tf_gemm.linear_concat2(a1, a2, w, bias)
+    y.backward(dy)
+    cat = torch.cat([t.detach().double() for t in (a1, a2) if t is not None], dim=1).requires_grad_(True)
+    wd, bd = w.detach().double().requires_grad_(True), bias.detach().double().requires_grad_(True)
+    yr = cat @ wd + bd
+    yr.backward(dy.double())
+    pairs = [("y", y, yr), ("dw", w.grad, wd.grad), ("db", bias.grad, bd.grad), ("da1", a1.grad, cat.grad[:, :K1])]
+    if K2:
+        pairs.append(("da2", a2.grad, cat.grad[:, K1:]))
+    for name, got, want in pairs:
+        scale = max(1e-6, float(want.abs().max()))
+        np.testing.assert_allclose(_n(got) / scale, _n(want.float()) / scale, rtol=2e-5, atol=2e-5, err_msg=name)
+    # through the dispatcher too
+    y2 = torch.ops.sph3d.pointwise_gemm_skinny(a1.detach(), a2.detach() if K2 else a1.new_empty(0), w.detach(), bias.detach())
+    assert torch.equal(y2, y.detach())
+    torch.library.opcheck(torch.ops.sph3d.pointwise_gemm_skinny, (a1.detach(), a2.detach() if K2 else a1.new_empty((R, 0)), w.detach(), bias.detach()),
+                          test_utils=("test_schema", "test_faketensor"))
+
+
+def test_skinny_layer_rejects_uncovered_shapes(dev):
+    from sph3d_gcn_amd import tf_gemm
+    assert not tf_gemm.skinny_supported(1024, 128, 128, 17)
+    assert not tf_gemm.skinny_supported(1024, 200, 128, 13)           # 328 > 256
+    assert not tf_gemm.skinny_supported(1024, 100, 0, 13)             # not a multiple of 16
+    assert not tf_gemm.skinny_supported(1024, 112, 144, 13)           # five started groups of 64 channels
+    with pytest.raises(RuntimeError, match="skinny"):
+        tf_gemm.linear_concat2(torch.randn(64, 100, device=dev), None, torch.randn(100, 13, device=dev))
+
+
+def test_logits_layer_without_concatenation_equals_concatenated_layer(dev):
+    """the S3DIS net with the logits layer reading its two halves in place == the net with the reference's concatenation:
+    same variables in the same order, same loss, same parameter gradients"""
+    cfg = s3dis_net.s3dis_config(2048)
+    pts, label, inner = (torch.from_numpy(a).to(dev) for a in synth.s3dis_batch(5, 2, 2048))
+
+    def run(fused):
+        s3g_util.FUSE_LOGITS_CONCAT = fused
+        torch.manual_seed(0)
+        model = s3dis_net.SPH3DS3DIS(cfg, device=dev, seed=3)
+        pred, end = model(pts, is_training=True)
+        loss = model.loss(pred, label, inner)
+        loss.backward()
+        names = [n for n, _ in model.named_parameters()]
+        grads = [p.grad.detach().clone() for _, p in model.named_parameters()]
+        return float(loss), names, grads, end['feats'].shape, [p.detach().clone() for _, p in model.named_parameters()]
+
+    try:
+        lf, nf, gf, sf, pf = run(True)
+        lu, nu, gu, su, pu = run(False)
+    finally:
+        s3g_util.FUSE_LOGITS_CONCAT = True
+    assert nf == nu and sf == su and tuple(sf[:2]) == (2, 2048)
+    for a, b in zip(pf, pu):
+        assert torch.equal(a, b)                                      # same initial values
+    assert abs(lf - lu) <= 1e-4 * max(1.0, abs(lu))
+    for n, a, b in zip(nf, gf, gu):
+        scale = max(1e-6, float(b.abs().max()))
+        np.testing.assert_allclose(_n(a) / scale, _n(b) / scale, rtol=2e-3, atol=2e-3, err_msg=n)
