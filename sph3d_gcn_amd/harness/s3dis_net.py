@@ -57,6 +57,12 @@ def normalize_xyz(points):
     return torch.cat((xy, z), dim=2)
 
 
+def _net_input(points, config):
+    xyz = points[:, :, 0:3]
+    norm_xyz = normalize_xyz(xyz) if config.normalize else xyz
+    return torch.cat((norm_xyz, points[:, :, 6:]), dim=2)
+
+
 def _separable_conv3d_block(net, list_channels, bin_size, nn_index, nn_count, filt_idx, name,
                             depth_multiplier=None, weight_decay=None, reuse=None, with_bn=True,
                             with_bias=True, is_training=None):
@@ -95,6 +101,7 @@ class GraphPlan:
         self._enc, self._dec = {}, {}
         self._enc_ev, self._dec_ev, self._pool_ev = {}, {}, {}
         self._synced = set()
+        self.net_input = None
         if self.use_side:
             self.main = torch.cuda.current_stream()
             streams = _side_stream.get(xyz.device)
@@ -125,6 +132,11 @@ class GraphPlan:
                 self.xyz_layers[0] = xyz
                 ev_xyz = torch.cuda.Event()
                 ev_xyz.record(s_fps)
+                # the network's input features (centred coordinates + colours, models/SPH3D_s3dis.py:11-19,38-41) depend on the
+                # batch only: prepared here, ahead of the feature path (one reduction + four small kernels, 60 us of main-stream time)
+                self.net_input = _net_input(points, config)
+                self._in_ev = torch.cuda.Event()
+                self._in_ev.record(s_fps)
                 self._sampling_chain(s_fps)
             s_graph.wait_event(ev_xyz)
             # every tensor the sampling stream allocated is read by kernels on the graph stream (neighbour search,
@@ -251,6 +263,13 @@ class GraphPlan:
                 t.record_stream(self.main)
         self._synced.add(key)
 
+    def input(self, points):
+        """centred coordinates + colours of the batch (prepared on the sampling stream when the plan runs on side streams)"""
+        if self.use_side and self.net_input is not None:
+            self._sync(("input",), self._in_ev, [self.net_input])
+            return self.net_input
+        return _net_input(points, self.config)
+
     def enc(self, l):
         """encoder level l: intra graph + bins of xyz_l"""
         if self.use_side:
@@ -292,14 +311,12 @@ def build_graphs(points, config, overlap=True):
 def get_model(points, is_training, config=None, graphs=None, points_ready=None):
     """models/SPH3D_s3dis.py:35-113 (config lists are not reversed in place here)."""
     end_points = {}
-    xyz = points[:, :, 0:3]
-    norm_xyz = normalize_xyz(xyz) if config.normalize else xyz
     reuse = None
-    net = torch.cat((norm_xyz, points[:, :, 6:]), dim=2)
+    plan = graphs if graphs is not None else GraphPlan(points, config, points_ready=points_ready)
+    net = plan.input(points)
     net = s3g_util.pointwise_conv3d(net, config.mlp, 'mlp1', weight_decay=config.weight_decay,
                                     with_bn=config.with_bn, with_bias=config.with_bias, reuse=reuse,
                                     is_training=is_training)
-    plan = graphs if graphs is not None else GraphPlan(points, config, points_ready=points_ready)
     encoder = []
     for l in range(len(config.radius)):
         g = plan.enc(l)
