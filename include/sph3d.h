@@ -377,6 +377,23 @@ size_t sph3d_pointwise_gemm_skinny_tn_workspace(int R, int K1, int K2, int N);
 int sph3d_pointwise_gemm_skinny_tn(int R, int K1, int K2, int N, const float* A1, const float* A2, const float* dY, float* dW,
                                    void* workspace, size_t workspace_bytes, sph3d_stream_t stream);
 
+/* ---- the depthwise convolution over a channel concatenation that is never materialised --------------------------------------
+ * DepthwiseConv3d / DepthwiseConv3dGrad (tf_conv3d.cpp:34-107, :109-205) applied to tf.concat((input_a, input_b), axis=2)
+ * (models/SPH3D_s3dis.py:100-104: a decoder level's un-pooled features and the encoder's skip features): input_a [B,N,Ca],
+ * input_b [B,N,Cb], filter [F, Ca+Cb, r], output [B,M,(Ca+Cb)*r]; the gradient writes grad_a [B,N,Ca] and grad_b [B,N,Cb]
+ * (workspace: sph3d_depthwise_conv3d_grad_t_workspace(B, N, F, Ca+Cb, r)).  The kernels' channel slices are 256 outputs wide and
+ * must lie inside one input: Ca*r a multiple of 256, Ca+Cb > 128, (Ca+Cb) % 4 == 0, r in {1,2}, F <= 33
+ * (..._cat_supported() -> 1 | 0; SPH3D_EUNSUPPORTED otherwise: concatenate and call the plain entries). */
+int sph3d_depthwise_conv3d_cat_supported(int F, int Ca, int Cb, int r);
+int sph3d_depthwise_conv3d_cat(int B, int N, int M, int F, int Ca, int Cb, int r, int K, const int* nn_index, const int* nn_count,
+                               const int* bin_index, const float* input_a, const float* input_b, const float* filter, float* output,
+                               sph3d_stream_t stream);
+int sph3d_depthwise_conv3d_grad_t_cat(int B, int N, int M, int F, int Ca, int Cb, int r, const int* offsets, const int* ent_key,
+                                      const float* ent_scale, const int* source_order, const int* active_bins, const float* input_a,
+                                      const float* input_b, const float* filter, const float* grad_output, float* grad_a,
+                                      float* grad_b, float* grad_filter, void* workspace, size_t workspace_bytes,
+                                      sph3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,9 @@ SIGNATURES = {
     "sph3d_build_sphere_graph_ocml": (_I, [_I, _I, _I, _I, _F, _I, _I, _I] + [_P] * 6 + [_P, _S, _P]),
     "sph3d_depthwise_conv3d_grad_t_workspace": (_S, [_I] * 5),
     "sph3d_depthwise_conv3d_grad_t": (_I, [_I] * 6 + [_P] * 10 + [_P, _S, _P]),
+    "sph3d_depthwise_conv3d_cat_supported": (_I, [_I] * 4),
+    "sph3d_depthwise_conv3d_cat": (_I, [_I] * 8 + [_P] * 8),
+    "sph3d_depthwise_conv3d_grad_t_cat": (_I, [_I] * 7 + [_P] * 12 + [_P, _S, _P]),
     "sph3d_spatial_order": (_I, [_I, _I, _P, _P, _P]),
     "sph3d_rows_by_bin": (_I, [_I] * 4 + [_P] * 6),
     "sph3d_tile_plan_sizes": (_I, [_I, _I, _I, _I, ctypes.c_longlong] + [_P] * 8),

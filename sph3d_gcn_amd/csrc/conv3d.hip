@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_row(
     int B, int N, int M, int F, int C, int K, int mblocks, int nslices,
     const int* __restrict__ nnIndex, const int* __restrict__ nnCount, const int* __restrict__ binIndex,
     const float* __restrict__ input, const float* __restrict__ filter, float* __restrict__ output,
-    const int* __restrict__ order)
+    const int* __restrict__ order, const float* __restrict__ input2 = nullptr, int Ca = 0)
 {
     extern __shared__ __attribute__((aligned(16))) float lfilt[];   // [F][SL]
     const int CR = C * R;
@@ -214,7 +214,14 @@ __global__ __launch_bounds__(256) void dwconv_fwd_row(
     (void)cin0;
     const int m_begin = mb * kFwdPointsPerWG;
     const int m_end = (m_begin + kFwdPointsPerWG) < M ? (m_begin + kFwdPointsPerWG) : M;
-    const float* inb = input + (size_t)b * N * C;
+    // input2 != nullptr: the input is the channel concatenation [input (Ca channels) | input2 (C - Ca)] of two tensors that were
+    // never concatenated (sph3d_depthwise_conv3d_cat: a decoder level's un-pooled features and the encoder's skip features).
+    // The launcher guarantees that a 256-output slice lies inside ONE of them, so the choice is per workgroup: a base
+    // pointer, a row stride and a channel shift.
+    const bool second = input2 != nullptr && (slice0 / R) >= Ca;
+    const int Cs = input2 == nullptr ? C : (second ? C - Ca : Ca);       // row stride of the source tensor
+    const int cshift = second ? Ca : 0;
+    const float* inb = (second ? input2 : input) + (size_t)b * N * Cs - cshift;
 
     for (int mi = m_begin + wave; mi < m_end; mi += 4) {
         // optional processing order: measured in round 1 (Morton order of the output points): no gain, the rows
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_row(
             binv = binv < 0 ? 0 : (binv >= F ? F - 1 : binv);     // out-of-range bin ids: same clamp as the transposed graph
             binv = myk < cnt ? binv : F;                           // ... times the zero row
             // element offsets of the input row and of the filter row, once per 64 edges (N * C < 2^32: checked by the launcher)
-            const unsigned noff = (unsigned)idxv * (unsigned)C;
+            const unsigned noff = (unsigned)idxv * (unsigned)Cs;
             const int foff = binv * (SL >> 2);                     // in float4 units: keeps the LDS read a 16-byte aligned ds_read_b128
             // ... then consumed eight at a time: 8 lane->scalar broadcasts, 8 independent row gathers and 8 filter
             // reads are in flight before the first FMA (the kernel is latency-bound otherwise).  kBatch divides 64, so
@@ -392,7 +399,8 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
     const int* __restrict__ offsets, const int* __restrict__ entKey, const float* __restrict__ entScale,
     const int* __restrict__ order, const int* __restrict__ activeBins, int compactMax,
     const float* __restrict__ input, const float* __restrict__ filter, const float* __restrict__ gradOutput,
-    float* __restrict__ gradInput, float* __restrict__ partial)
+    float* __restrict__ gradInput, float* __restrict__ partial,
+    const float* __restrict__ input2 = nullptr, float* __restrict__ gradInput2 = nullptr, int Ca = 0)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int SLW = 64 * V;                 // slice width in output channels
@@ -409,6 +417,12 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
     const int slice0 = slice * SLW;
     const int SL = (CR - slice0) < SLW ? (CR - slice0) : SLW;     // multiple of V
     float* lfilt = lds;                                           // [F][SL]
+    // input2 != nullptr: input / gradInput are the two halves [Ca | C - Ca] of a channel concatenation that was never made
+    // (sph3d_depthwise_conv3d_grad_t_cat); a slice lies inside one of them (launcher), so the choice is per workgroup
+    const bool second = input2 != nullptr && (slice0 / R) >= Ca;
+    const int Cs = input2 == nullptr ? C : (second ? C - Ca : Ca);
+    const float* __restrict__ xin = (second ? input2 : input) - (second ? Ca : 0);
+    float* __restrict__ gin = (second ? gradInput2 : gradInput) - (second ? Ca : 0);
 
     for (int e = threadIdx.x * V; e < F * SL; e += blockDim.x * V) {
         const int f = e / SL;
@@ -466,7 +480,7 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
         const int ov1 = (MAXF >= 64) ? o[(64 + lane) <= F ? (64 + lane) : F] : 0;
         float xi[VI], xv[V];
 #pragma unroll
-        for (int u = 0; u < VI; u++) xi[u] = input[((size_t)b * N + n) * C + (act ? cin0 : slice0 / R) + u];
+        for (int u = 0; u < VI; u++) xi[u] = xin[((size_t)b * N + n) * Cs + (act ? cin0 : slice0 / R) + u];
 #pragma unroll
         for (int v = 0; v < V; v++) xv[v] = xi[(V >= R) ? v / R : 0];
         float gi[V];
@@ -598,7 +612,7 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
             for (int v = 0; v < V; v++) gi[v] += __shfl_xor(gi[v], 32);
         }
         if (act && half == 0) {
-            float* gp = &gradInput[((size_t)b * N + n) * C + cin0];
+            float* gp = &gin[((size_t)b * N + n) * Cs + cin0];
             if (V >= R) {
 #pragma unroll
                 for (int u = 0; u < VI; u++) {
@@ -938,7 +952,7 @@ template <int R, int V, int MAXF, bool HALF>
 static int launch_bwd_t_vec(int B, int N, int M, int F, int C, const int* offsets, const int* ent_key,
                             const float* ent_scale, const int* order, const int* active_bins, const float* input,
                             const float* filter, const float* grad_output, float* grad_input, float* grad_filter,
-                            float* partial, hipStream_t st)
+                            float* partial, hipStream_t st, const float* input2 = nullptr, float* grad_input2 = nullptr, int Ca = 0)
 {
     const int CR = C * R;
     const int SLW = 64 * V;
@@ -965,11 +979,11 @@ static int launch_bwd_t_vec(int B, int N, int M, int F, int C, const int* offset
         bwd_plan(B, N, nslices, 4, pc, Wc);
         hipLaunchKernelGGL(kernc, dim3(8 * Wc * nslices), dim3(kBwdTWaves * 64), lds, st, B, N, M, F, C,
                            Wc, pc, nslices, offsets, ent_key, ent_scale, order, ab, kCompactBins, input, filter, grad_output,
-                           grad_input, partial);
+                           grad_input, partial, input2, grad_input2, Ca);
     }
     hipLaunchKernelGGL(kern, dim3(8 * W * nslices), dim3(kBwdTWaves * 64), lds, st, B, N, M, F, C,
                        W, parts, nslices, offsets, ent_key, ent_scale, order, ab, kCompactBins, input, filter, grad_output,
-                       grad_input, partial);
+                       grad_input, partial, input2, grad_input2, Ca);
     const int total = F * CR;
     hipLaunchKernelGGL(reduce_filter_partials, dim3((total + 31) / 32), dim3(1024), 0, st, 8 * W, total, CR, partial,
                        grad_filter, ab, kCompactBins, 8 * Wc);
@@ -1055,4 +1069,78 @@ extern "C" int sph3d_depthwise_conv3d_grad(int B, int N, int M, int F, int C, in
     if (rc) return rc;
     return sph3d_depthwise_conv3d_grad_t(B, N, M, F, C, r, t.offsets, t.key, t.scale, nullptr, t.active, input, filter, grad_output,
                                          grad_input, grad_filter, (char*)workspace + tg, workspace_bytes - tg, stream);
+}
+
+
+// ---- the same two ops on a channel concatenation [input_a (Ca) | input_b (Cb)] that is never materialised ---------------------
+// (models/SPH3D_s3dis.py:100-104: tf.concat of the un-pooled features and the encoder's skip features feeds the next decoder
+// level's separable convolution).  Channel slices of the kernels are 256 outputs = 256 / r inputs wide; Ca * r must be a
+// multiple of 256 so that every slice reads one tensor.  Other shapes: SPH3D_EUNSUPPORTED (concatenate and call the plain ops).
+static bool cat_ok(int F, int Ca, int Cb, int r)
+{
+    int V = 0;
+    const int C = Ca + Cb;
+    return Ca > 0 && Cb > 0 && (r == 1 || r == 2) && C % 4 == 0 && C > 128 && (Ca * r) % kSlice == 0 && vec_plan(F, C * r, r, V) && V == 4;
+}
+
+extern "C" int sph3d_depthwise_conv3d_cat_supported(int F, int Ca, int Cb, int r) { return cat_ok(F, Ca, Cb, r) ? 1 : 0; }
+
+extern "C" int sph3d_depthwise_conv3d_cat(int B, int N, int M, int F, int Ca, int Cb, int r, int K, const int* nn_index,
+                                          const int* nn_count, const int* bin_index, const float* input_a, const float* input_b,
+                                          const float* filter, float* output, sph3d_stream_t stream)
+{
+    const int C = Ca + Cb;
+    int rc = conv_dims_ok(B, N, M, F, C, r, K, "DepthwiseConv3d");
+    if (rc) return rc;
+    if (!cat_ok(F, Ca, Cb, r) || (unsigned long long)N * C + 256ull >= (1ull << 32)) {
+        set_error("DepthwiseConv3d (two inputs): Ca=%d Cb=%d r=%d not covered (Ca*r must be a multiple of 256)", Ca, Cb, r);
+        return SPH3D_EUNSUPPORTED;
+    }
+    if (B == 0 || M == 0) return SPH3D_OK;
+    hipStream_t st = as_stream(stream);
+    const int CR = C * r;
+    const int mblocks = (M + kFwdPointsPerWG - 1) / kFwdPointsPerWG;
+    const int nslices = (CR + kSlice - 1) / kSlice;
+    const size_t lds = (size_t)(F + 1) * kSlice * sizeof(float);
+    const dim3 grid(xcd_grid(B, mblocks * nslices));
+    auto launch = [&](auto kern) -> int {
+        if (lds > 64 * 1024) {
+            int e = check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "conv3d: hipFuncSetAttribute");
+            if (e) return e;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, B, N, M, F, C, K, mblocks, nslices, nn_index, nn_count, bin_index, input_a,
+                           filter, output, nullptr, input_b, Ca);
+        return 0;
+    };
+    rc = r == 2 ? launch(dwconv_fwd_row<2>) : launch(dwconv_fwd_row<1>);
+    if (rc) return rc;
+    return check_launch("sph3d_depthwise_conv3d_cat");
+}
+
+extern "C" int sph3d_depthwise_conv3d_grad_t_cat(int B, int N, int M, int F, int Ca, int Cb, int r, const int* offsets, const int* ent_key,
+                                                 const float* ent_scale, const int* source_order, const int* active_bins,
+                                                 const float* input_a, const float* input_b, const float* filter,
+                                                 const float* grad_output, float* grad_a, float* grad_b, float* grad_filter,
+                                                 void* workspace, size_t workspace_bytes, sph3d_stream_t stream)
+{
+    const int C = Ca + Cb;
+    int rc = conv_dims_ok(B, N, M, F, C, r, 1, "DepthwiseConv3dGrad");
+    if (rc) return rc;
+    if (!cat_ok(F, Ca, Cb, r) || (unsigned long long)M * C * r + 256ull >= (1ull << 32)) {
+        set_error("DepthwiseConv3dGrad (two inputs): Ca=%d Cb=%d r=%d not covered (Ca*r must be a multiple of 256)", Ca, Cb, r);
+        return SPH3D_EUNSUPPORTED;
+    }
+    hipStream_t st = as_stream(stream);
+    if (B == 0) return check_hip(hipMemsetAsync(grad_filter, 0, sizeof(float) * (size_t)F * C * r, st), "conv3d grad: memset");
+    const size_t need = sph3d_depthwise_conv3d_grad_t_workspace(B, N, F, C, r);
+    if (workspace == nullptr || workspace_bytes < need) {
+        set_error("DepthwiseConv3dGrad: workspace %zu B < required %zu B", workspace_bytes, need);
+        return SPH3D_EWORKSPACE;
+    }
+    float* partial = (float*)workspace;
+    if (r == 2)
+        return launch_bwd_t_vec<2, 4, 33, false>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, active_bins, input_a, filter,
+                                                 grad_output, grad_a, grad_filter, partial, st, input_b, grad_b, Ca);
+    return launch_bwd_t_vec<1, 4, 33, false>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, active_bins, input_a, filter,
+                                             grad_output, grad_a, grad_filter, partial, st, input_b, grad_b, Ca);
 }

@@ -341,7 +341,9 @@ def get_model(points, is_training, config=None, graphs=None, points_ready=None):
         net = s3g_util.unpool3d(net, g["inter_idx"], g["inter_cnt"], g["inter_dst"], method=config.unpool_method,
                                 scope='unpool' + str(l + 1))
         if l + 1 < len(channels):
-            net = torch.cat((net, encoder[l]), dim=2)
+            # tf.concat((net, encoder[l]), axis=2) (models/SPH3D_s3dis.py:100-104) feeds the next level's separable convolution,
+            # which takes the pair as it is (s3g_util.separable_conv3d: the depthwise kernels read both tensors in place)
+            net = (net, encoder[l])
     # the last concatenation (models/SPH3D_s3dis.py:104) feeds only the logits layer: that layer reads its two halves in place
     # (s3g_util.pointwise_conv3d_concat); end_points['feats'] materialises the concatenation when somebody asks for it
     end_points = _EndPoints(end_points)

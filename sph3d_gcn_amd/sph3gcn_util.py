@@ -279,11 +279,27 @@ def separable_conv3d(inputs,
                      is_training=None):
     """Separable spherical convolution layer (same signature as utils/sph3gcn_util.py:88-163): depthwise conv over the
     graph, pointwise GEMM to `num_output_channels`, then bias / activation / batch norm as the flags say."""
-    num_in_channels = inputs.shape[-1]
+    # inputs may be a PAIR (a, b): the layer of the reference applied to tf.concat((a, b), axis=2) — same variables, same result —
+    # with the depthwise kernels reading the two tensors in place (tf_conv3d.depthwise_conv3d_concat)
+    pair = inputs if isinstance(inputs, (tuple, list)) else None
+    if pair is not None:
+        supported = getattr(tf_conv3d, "concat_supported", None)       # (the oracle-backed CPU stand-ins of the tests have none)
+        if not (FUSE_CONV_CONCAT and pair[0].is_cuda and supported is not None and supported(pair[0], pair[1], torch.empty(
+                (kernel_size, pair[0].shape[-1] + pair[1].shape[-1], depth_multiplier), device='meta'))):
+            inputs, pair = torch.cat(tuple(pair), dim=2), None
+    num_in_channels = inputs.shape[-1] if pair is None else pair[0].shape[-1] + pair[1].shape[-1]
     depthwise_kernel = _variable_with_weight_decay(scope + '/depthwise_weights',
                                                    shape=[kernel_size, num_in_channels, depth_multiplier],
                                                    use_xavier=use_xavier, stddev=stddev,
                                                    with_decay=weight_decay)
+    if pair is not None:
+        outputs = tf_conv3d.depthwise_conv3d_concat(pair[0], pair[1], depthwise_kernel, nn_index, nn_count, filt_index)
+        batch_size = outputs.shape[0]
+        num_in_channels = outputs.shape[-1]
+        kernel = _variable_with_weight_decay(scope + '/weights', shape=[num_in_channels, num_out_channels],
+                                             use_xavier=use_xavier, stddev=stddev, with_decay=weight_decay)
+        return _gemm_tail(outputs.reshape(-1, num_in_channels), kernel, (batch_size, -1, num_out_channels), num_out_channels, scope,
+                          activation_fn, with_bn, with_bias, reuse, is_training)
     if (FUSE_SEPARABLE_INFERENCE and is_training is not None and not bool(is_training) and not torch.is_grad_enabled()
             and (activation_fn is elu or activation_fn is None)
             and tf_conv3d.separable_fused_supported(inputs, depthwise_kernel, nn_index, num_out_channels)):
@@ -394,6 +410,7 @@ def unpool3d(inputs, nn_index, nn_count, nn_dist, scope, method):
 
 
 FUSE_GEMM_BN = True    # the statistics of that tail from the GEMM's epilogue where the shape allows (tf_norm.gemm_elu_batch_norm)
+FUSE_CONV_CONCAT = True           # separable_conv3d((a, b), ...): depthwise kernels over two inputs in place (tf_conv3d.depthwise_conv3d_concat)
 FUSE_LOGITS_CONCAT = True         # pointwise_conv3d_concat: few-output layer over two operand halves (tf_gemm.linear_concat2)
 FUSE_SEPARABLE_INFERENCE = True   # is_training=False under torch.no_grad(): separable_conv3d as ONE kernel (tf_conv3d.separable_conv3d_fused)
 FUSE_ELU_BN = True     # fused sph3d::elu_bn for the ELU -> BN tail (same variables / moving statistics as the unfused ops)

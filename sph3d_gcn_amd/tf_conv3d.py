@@ -203,3 +203,67 @@ def separable_conv3d_fused(input, filter, weights, nn_index, nn_count, bin_index
     with torch.no_grad():
         return _separable_conv3d_fused_impl(input, filter, weights, e if bias is None else bias, e if scale is None else scale,
                                             e if shift is None else shift, 1 if elu else 0, nn_index, nn_count, bin_index)
+
+
+# ---- the depthwise convolution over a channel concatenation [a | b] that is never materialised (a decoder level's input) ------
+def concat_supported(input_a, input_b, filter):
+    if not (input_a.is_cuda and input_b.is_cuda and input_a.dim() == 3 and input_a.shape[:2] == input_b.shape[:2] and filter.dim() == 3):
+        return False
+    return bool(_lib.lib().sph3d_depthwise_conv3d_cat_supported(filter.shape[0], input_a.shape[2], input_b.shape[2], filter.shape[2]))
+
+
+def _depthwise_conv3d_cat_impl(input_a, input_b, filter, nn_index, nn_count, bin_index):
+    _lib.require_device(input_a, input_b, filter, nn_index, nn_count, bin_index)
+    input_a, input_b, filter = _lib.f32(input_a), _lib.f32(input_b), _lib.f32(filter)
+    nn_index, nn_count, bin_index = _lib.i32(nn_index), _lib.i32(nn_count), _lib.i32(bin_index)
+    B, N, Ca = input_a.shape
+    Cb = input_b.shape[2]
+    F, Cf, r = filter.shape
+    if Cf != Ca + Cb:
+        raise ValueError("Input Channel Size error!")
+    M, K = nn_index.shape[1], nn_index.shape[2]
+    output = torch.empty((B, M, (Ca + Cb) * r), dtype=torch.float32, device=input_a.device)
+    _lib.check(_lib.lib().sph3d_depthwise_conv3d_cat(B, N, M, F, Ca, Cb, r, K, _lib.ptr(nn_index), _lib.ptr(nn_count),
+                                                     _lib.ptr(bin_index), _lib.ptr(input_a), _lib.ptr(input_b), _lib.ptr(filter),
+                                                     _lib.ptr(output), _lib.stream_ptr()))
+    return output
+
+
+def _depthwise_conv3d_cat_grad_impl(input_a, input_b, filter, grad_output, nn_index, nn_count, bin_index):
+    input_a, input_b, filter, grad_output = _lib.f32(input_a), _lib.f32(input_b), _lib.f32(filter), _lib.f32(grad_output)
+    nn_index, nn_count, bin_index = _lib.i32(nn_index), _lib.i32(nn_count), _lib.i32(bin_index)
+    B, N, Ca = input_a.shape
+    Cb = input_b.shape[2]
+    F, _, r = filter.shape
+    M = nn_index.shape[1]
+    grad_a, grad_b, grad_filter = torch.empty_like(input_a), torch.empty_like(input_b), torch.empty_like(filter)
+    offsets, ent_key, ent_scale, active = _tgraph.transpose(nn_index, nn_count, N, bin_index=bin_index, num_bins=F)
+    l = _lib.lib()
+    wsb = l.sph3d_depthwise_conv3d_grad_t_workspace(B, N, F, Ca + Cb, r)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=input_a.device) if wsb else None
+    _lib.check(l.sph3d_depthwise_conv3d_grad_t_cat(
+        B, N, M, F, Ca, Cb, r, _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale), _lib.ptr(_tgraph.source_order(nn_index)),
+        _lib.ptr(active), _lib.ptr(input_a), _lib.ptr(input_b), _lib.ptr(filter), _lib.ptr(grad_output), _lib.ptr(grad_a),
+        _lib.ptr(grad_b), _lib.ptr(grad_filter), _lib.ptr(ws), wsb, _lib.stream_ptr()))
+    return grad_a, grad_b, grad_filter
+
+
+class _DepthwiseConv3dCatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input_a, input_b, filter, nn_index, nn_count, bin_index):
+        ctx.save_for_backward(input_a, input_b, filter, nn_index, nn_count, bin_index)
+        return _depthwise_conv3d_cat_impl(input_a, input_b, filter, nn_index, nn_count, bin_index)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input_a, input_b, filter, nn_index, nn_count, bin_index = ctx.saved_tensors
+        ga, gb, gf = _depthwise_conv3d_cat_grad_impl(input_a, input_b, filter, grad_output, nn_index, nn_count, bin_index)
+        return ga, gb, gf, None, None, None
+
+
+def depthwise_conv3d_concat(input_a, input_b, filter, nn_index, nn_count, bin_index):
+    """depthwise_conv3d(torch.cat((input_a, input_b), 2), filter, ...) without the concatenation (and without slicing its gradient):
+    the kernels read / write the two tensors in place.  Shapes outside concat_supported(): concatenate, then the plain op."""
+    if concat_supported(input_a, input_b, filter):
+        return _DepthwiseConv3dCatFn.apply(input_a, input_b, filter, nn_index, nn_count, bin_index)
+    return depthwise_conv3d(torch.cat((input_a, input_b), dim=2), filter, nn_index, nn_count, bin_index)

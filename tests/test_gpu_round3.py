@@ -629,14 +629,15 @@ def test_skinny_layer_rejects_uncovered_shapes(dev):
         tf_gemm.linear_concat2(torch.randn(64, 100, device=dev), None, torch.randn(100, 13, device=dev))
 
 
-def test_logits_layer_without_concatenation_equals_concatenated_layer(dev):
-    """the S3DIS net with the logits layer reading its two halves in place == the net with the reference's concatenation:
-    same variables in the same order, same loss, same parameter gradients"""
+@pytest.mark.parametrize("flag", ["FUSE_LOGITS_CONCAT", "FUSE_CONV_CONCAT"])
+def test_logits_layer_without_concatenation_equals_concatenated_layer(dev, flag):
+    """the S3DIS net with the logits layer (the decoder's separable convolutions) reading its two inputs in place == the net with
+    the reference's concatenations: same variables in the same order, same loss, same parameter gradients"""
     cfg = s3dis_net.s3dis_config(2048)
     pts, label, inner = (torch.from_numpy(a).to(dev) for a in synth.s3dis_batch(5, 2, 2048))
 
     def run(fused):
-        s3g_util.FUSE_LOGITS_CONCAT = fused
+        setattr(s3g_util, flag, fused)
         torch.manual_seed(0)
         model = s3dis_net.SPH3DS3DIS(cfg, device=dev, seed=3)
         pred, end = model(pts, is_training=True)
@@ -650,7 +651,7 @@ def test_logits_layer_without_concatenation_equals_concatenated_layer(dev):
         lf, nf, gf, sf, pf = run(True)
         lu, nu, gu, su, pu = run(False)
     finally:
-        s3g_util.FUSE_LOGITS_CONCAT = True
+        setattr(s3g_util, flag, True)
     assert nf == nu and sf == su and tuple(sf[:2]) == (2, 2048)
     for a, b in zip(pf, pu):
         assert torch.equal(a, b)                                      # same initial values
@@ -658,3 +659,41 @@ def test_logits_layer_without_concatenation_equals_concatenated_layer(dev):
     for n, a, b in zip(nf, gf, gu):
         scale = max(1e-6, float(b.abs().max()))
         np.testing.assert_allclose(_n(a) / scale, _n(b) / scale, rtol=2e-3, atol=2e-3, err_msg=n)
+
+
+# ---- the depthwise convolution over a channel concatenation that is never materialised --------------------------------------
+@pytest.mark.parametrize("case", [(2, 700, 700, 256, 128, 2, 32), (3, 500, 200, 128, 256, 2, 24), (1, 384, 384, 512, 512, 1, 64),
+                                  (16, 128, 128, 256, 256, 2, 16)], ids=lambda c: "B%d-N%d-M%d-Ca%d-Cb%d-r%d-K%d" % c)
+def test_depthwise_conv_over_two_inputs_equals_concatenated_input(dev, case):
+    B, N, M, Ca, Cb, r, K = case
+    rng = np.random.RandomState(Ca + Cb + r)
+    xyz = _t(rng.rand(B, N, 3).astype(np.float32), dev)
+    q = xyz[:, :M].contiguous()
+    idx, cnt, dst = tf_nnquery.build_sphere_neighbor(xyz, q, 0.25, None, K)
+    filt = tf_buildkernel.spherical_kernel(xyz, q, idx, cnt, dst, 0.25, [8, 2, 2])
+    a = _t(rng.randn(B, N, Ca).astype(np.float32), dev).requires_grad_(True)
+    b = _t(rng.randn(B, N, Cb).astype(np.float32), dev).requires_grad_(True)
+    w = _t(rng.randn(33, Ca + Cb, r).astype(np.float32), dev).requires_grad_(True)
+    go = _t(rng.randn(B, M, (Ca + Cb) * r).astype(np.float32), dev)
+    assert tf_conv3d.concat_supported(a, b, w)
+    out = tf_conv3d.depthwise_conv3d_concat(a, b, w, idx, cnt, filt)
+    out.backward(go)
+    a2, b2, w2 = (t.detach().clone().requires_grad_(True) for t in (a, b, w))
+    ref = tf_conv3d.depthwise_conv3d(torch.cat((a2, b2), dim=2), w2, idx, cnt, filt)
+    ref.backward(go)
+    assert torch.equal(out, ref)                                     # same kernel arithmetic, same order
+    for name, g, gr in (("a", a.grad, a2.grad), ("b", b.grad, b2.grad), ("w", w.grad, w2.grad)):
+        np.testing.assert_allclose(_n(g), _n(gr), rtol=1e-6, atol=1e-6, err_msg=name)
+    out_o = oracle.depthwise_conv3d(np.concatenate((_n(a), _n(b)), axis=2), _n(w), _n(idx), _n(cnt), _n(filt))
+    np.testing.assert_allclose(_n(out), out_o, **TOL)
+
+
+def test_depthwise_conv_over_two_inputs_falls_back_where_slices_would_straddle(dev):
+    a, b = torch.randn(1, 64, 64, device=dev), torch.randn(1, 64, 256, device=dev)       # Ca * r = 128: not a multiple of 256
+    w = torch.randn(33, 320, 2, device=dev)
+    assert not tf_conv3d.concat_supported(a, b, w)
+    xyz = torch.rand(1, 64, 3, device=dev)
+    idx, cnt, dst = tf_nnquery.build_sphere_neighbor(xyz, xyz, 0.5, None, 16)
+    filt = tf_buildkernel.spherical_kernel(xyz, xyz, idx, cnt, dst, 0.5, [8, 2, 2])
+    out = tf_conv3d.depthwise_conv3d_concat(a, b, w, idx, cnt, filt)
+    assert torch.equal(out, tf_conv3d.depthwise_conv3d(torch.cat((a, b), 2), w, idx, cnt, filt))
