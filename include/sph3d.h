@@ -205,7 +205,9 @@ int sph3d_max_pool3d_grad(int B, int N, int M, int C,
  * the pooling graph's nn_index / nn_count): no memset, no float atomics, fixed summation order.  nn_count [B,M]: rows
  * without neighbours carry max_index 0 and their gradient goes to point 0, as in the scatter form. */
 int sph3d_max_pool3d_grad_t(int B, int N, int M, int C, const int* offsets, const int* ent_key, const int* nn_count,
-                            const int* max_index, const float* grad_output, float* grad_input, sph3d_stream_t stream);
+                            const int* max_index, const float* grad_output,
+                            const float* addend /* optional [B,N,C]: another gradient of the same input, added in (NULL: none) */,
+                            float* grad_input, sph3d_stream_t stream);
 int sph3d_avg_pool3d(int B, int N, int M, int C, int K,
                      const int* nn_index, const int* nn_count, const float* input,
                      float* output, sph3d_stream_t stream);

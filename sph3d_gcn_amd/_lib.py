@@ -34,7 +34,7 @@ SIGNATURES = {
     "sph3d_depthwise_conv3d_grad": (_I, [_I] * 7 + [_P] * 8 + [_P, _S, _P]),
     "sph3d_max_pool3d": (_I, [_I] * 5 + [_P] * 6),
     "sph3d_max_pool3d_grad": (_I, [_I] * 4 + [_P] * 4),
-    "sph3d_max_pool3d_grad_t": (_I, [_I] * 4 + [_P] * 7),
+    "sph3d_max_pool3d_grad_t": (_I, [_I] * 4 + [_P] * 8),
     "sph3d_avg_pool3d": (_I, [_I] * 5 + [_P] * 5),
     "sph3d_avg_pool3d_grad": (_I, [_I] * 5 + [_P] * 4 + [_P, _S, _P]),
     "sph3d_graph_balanced_order": (_I, [_I, _I, _I, _P, _P, _P]),

@@ -262,7 +262,8 @@ template <int V>
 __global__ __launch_bounds__(256) void maxpool_bwd_t(
     int B, int Nin, int Mout, int C, int nblocks, int ppwg,
     const int* __restrict__ offsets, const int* __restrict__ entKey, const int* __restrict__ nnCount,
-    const int* __restrict__ maxIndex, const float* __restrict__ gradOutput, float* __restrict__ gradInput)
+    const int* __restrict__ maxIndex, const float* __restrict__ gradOutput, const float* __restrict__ addend,
+    float* __restrict__ gradInput)
 {
     int b, nb;
     xcd_decode((int)blockIdx.x, B, nblocks, b, nb);
@@ -280,9 +281,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_t(
             const int c = c0 + lane * V;
             const bool act = c < C;
             const int cc = act ? c : 0;
+            // addend (optional, [B, Nin, C]): a second gradient of the same tensor — the pooled tensor's other consumer, the
+            // encoder's skip connection — summed here instead of by a separate elementwise kernel over three tensors
             float acc[V];
 #pragma unroll
-            for (int v = 0; v < V; v++) acc[v] = 0.f;
+            for (int v = 0; v < V; v++) acc[v] = addend != nullptr ? addend[((size_t)b * Nin + n) * C + cc + v] : 0.f;
             auto take = [&](int m) {       // branch-free: inactive lanes read channel 0
                 if (V == 4) {
                     const int4 a = *reinterpret_cast<const int4*>(&mib[(size_t)m * C + cc]);
@@ -478,7 +481,8 @@ extern "C" int sph3d_max_pool3d_grad(int B, int N, int M, int C, const int* max_
 }
 
 extern "C" int sph3d_max_pool3d_grad_t(int B, int N, int M, int C, const int* offsets, const int* ent_key, const int* nn_count,
-                                       const int* max_index, const float* grad_output, float* grad_input, sph3d_stream_t stream)
+                                       const int* max_index, const float* grad_output, const float* addend, float* grad_input,
+                                       sph3d_stream_t stream)
 {
     SPH3D_REQUIRE(B >= 0 && N > 0 && M >= 0 && C > 0, "MaxPool3dGrad: bad dims B=%d N=%d M=%d C=%d", B, N, M, C);
     if (B == 0) return SPH3D_OK;
@@ -488,10 +492,10 @@ extern "C" int sph3d_max_pool3d_grad_t(int B, int N, int M, int C, const int* of
     const dim3 grid(xcd_grid(B, nblocks));
     if (C % 4 == 0)
         hipLaunchKernelGGL(maxpool_bwd_t<4>, grid, dim3(256), 0, st, B, N, M, C, nblocks, ppwg, offsets, ent_key, nn_count, max_index,
-                           grad_output, grad_input);
+                           grad_output, addend, grad_input);
     else
         hipLaunchKernelGGL(maxpool_bwd_t<1>, grid, dim3(256), 0, st, B, N, M, C, nblocks, ppwg, offsets, ent_key, nn_count, max_index,
-                           grad_output, grad_input);
+                           grad_output, addend, grad_input);
     return check_launch("sph3d_max_pool3d_grad_t");
 }
 

@@ -324,11 +324,14 @@ def get_model(points, is_training, config=None, graphs=None, points_ready=None):
                                       g["filt_idx"], 'conv' + str(l + 1), config.multiplier[l], reuse=reuse,
                                       weight_decay=config.weight_decay, with_bn=config.with_bn,
                                       with_bias=config.with_bias, is_training=is_training)
-        encoder.append(net)
         if config.num_sample[l] > 1:
             g = plan.pool(l)
-            net = s3g_util.pool3d(net, g["inter_idx"], g["inter_cnt"], method=config.pool_method,
-                                  scope='pool' + str(l + 1))
+            # the level's features go to the pooling AND, as the skip connection, to the decoder (models/SPH3D_s3dis.py:60-72)
+            net, skip = s3g_util.pool3d_with_skip(net, g["inter_idx"], g["inter_cnt"], method=config.pool_method,
+                                                  scope='pool' + str(l + 1))
+            encoder.append(skip)
+        else:
+            encoder.append(net)
     channels = list(reversed(config.channels))
     multiplier = list(reversed(config.multiplier))
     encoder.reverse()

@@ -394,6 +394,16 @@ def pool3d(inputs, nn_index, nn_count, scope, method):
     return outputs
 
 
+def pool3d_with_skip(inputs, nn_index, nn_count, scope, method):
+    """pool3d(inputs, ...) for an `inputs` that a skip connection uses too: -> (pooled, skip).  `skip` is `inputs`; with max pooling
+    on the GPU the two gradients of `inputs` are summed inside the pooling gradient's kernel (tf_pool3d.max_pool3d_with_skip)."""
+    fn = getattr(tf_pool3d, "max_pool3d_with_skip", None)        # (the oracle-backed CPU stand-ins of the tests have none)
+    if method == 'max' and FUSE_POOL_SKIP and inputs.is_cuda and fn is not None:
+        outputs, _max_index, skip = fn(inputs, nn_index, nn_count)
+        return outputs, skip
+    return pool3d(inputs, nn_index, nn_count, scope, method), inputs
+
+
 def unpool3d(inputs, nn_index, nn_count, nn_dist, scope, method):
     """Feature interpolation back onto the finer point set, method 'mean' or 'weighted' (same signature as
     utils/sph3gcn_util.py:300-325)."""
@@ -410,6 +420,7 @@ def unpool3d(inputs, nn_index, nn_count, nn_dist, scope, method):
 
 
 FUSE_GEMM_BN = True    # the statistics of that tail from the GEMM's epilogue where the shape allows (tf_norm.gemm_elu_batch_norm)
+FUSE_POOL_SKIP = True             # pool3d_with_skip: the skip connection's gradient is added inside the max-pool gradient kernel
 FUSE_CONV_CONCAT = True           # separable_conv3d((a, b), ...): depthwise kernels over two inputs in place (tf_conv3d.depthwise_conv3d_concat)
 FUSE_LOGITS_CONCAT = True         # pointwise_conv3d_concat: few-output layer over two operand halves (tf_gemm.linear_concat2)
 FUSE_SEPARABLE_INFERENCE = True   # is_training=False under torch.no_grad(): separable_conv3d as ONE kernel (tf_conv3d.separable_conv3d_fused)

@@ -126,14 +126,16 @@ def _avg_backward(ctx, grad_output):
 _avg_pool3d.register_autograd(_avg_backward, setup_context=_avg_setup)
 
 
-def _max_pool3d_grad_t_impl(input, grad_output, max_index, nn_count, tg):
-    """the gradient as a gather over the transposed pooling graph tg = (offsets, ent_key, ...) (sph3d_max_pool3d_grad_t)"""
+def _max_pool3d_grad_t_impl(input, grad_output, max_index, nn_count, tg, addend=None):
+    """the gradient as a gather over the transposed pooling graph tg = (offsets, ent_key, ...) (sph3d_max_pool3d_grad_t);
+    addend: another gradient of `input` ([B,N,C]), added in by the same kernel"""
     grad_output, max_index = _lib.f32(grad_output), _lib.i32(max_index)
+    addend = None if addend is None else _lib.f32(addend)
     B, N, C = input.shape
     M = grad_output.shape[1]
     grad_input = torch.empty((B, N, C), dtype=torch.float32, device=input.device)
     _lib.check(_lib.lib().sph3d_max_pool3d_grad_t(B, N, M, C, _lib.ptr(tg[0]), _lib.ptr(tg[1]), _lib.ptr(nn_count),
-                                                  _lib.ptr(max_index), _lib.ptr(grad_output), _lib.ptr(grad_input),
+                                                  _lib.ptr(max_index), _lib.ptr(grad_output), _lib.ptr(addend), _lib.ptr(grad_input),
                                                   _lib.stream_ptr()))
     return grad_input
 
@@ -173,6 +175,38 @@ class _AvgPool3dFn(torch.autograd.Function):
 
 def max_pool3d(input, nn_index, nn_count):
     return _MaxPool3dFn.apply(input, nn_index, nn_count)
+
+
+class _MaxPool3dSkipFn(torch.autograd.Function):
+    """max_pool3d whose input is ALSO used by a skip connection: returns (pooled, max_index, input as the skip tensor); the two
+    gradients of the input — through the pooling and through the skip — meet inside the pooling gradient's gather kernel
+    instead of in autograd's elementwise accumulation (three tensors through memory)."""
+
+    @staticmethod
+    def forward(ctx, input, nn_index, nn_count):
+        output, max_index = _max_pool3d_impl(input, nn_index, nn_count)
+        ctx.save_for_backward(input, max_index, nn_index, nn_count)
+        ctx.mark_non_differentiable(max_index)
+        return output, max_index, input.view_as(input)
+
+    @staticmethod
+    def backward(ctx, grad_output, grad_index, grad_skip):
+        input, max_index, nn_index, nn_count = ctx.saved_tensors
+        tg = None
+        if input.is_cuda and nn_index.dtype == torch.int32 and nn_count.dtype == torch.int32:
+            tg = _tgraph.peek(nn_index, nn_count, input.shape[1])
+        if grad_output is None:
+            return grad_skip, None, None
+        if tg is not None:
+            skip = grad_skip.contiguous() if grad_skip is not None else None
+            return _max_pool3d_grad_t_impl(input, grad_output, max_index, nn_count, tg, addend=skip), None, None
+        g = _max_pool3d_grad_impl(input, grad_output, max_index)
+        return (g if grad_skip is None else g + grad_skip), None, None
+
+
+def max_pool3d_with_skip(input, nn_index, nn_count):
+    """-> (pooled, max_index, skip): `skip` is `input` for whoever else consumes it (see _MaxPool3dSkipFn)"""
+    return _MaxPool3dSkipFn.apply(input, nn_index, nn_count)
 
 
 def max_pool3d_grad(input, grad_output, max_index):

@@ -697,3 +697,35 @@ def test_depthwise_conv_over_two_inputs_falls_back_where_slices_would_straddle(d
     filt = tf_buildkernel.spherical_kernel(xyz, xyz, idx, cnt, dst, 0.5, [8, 2, 2])
     out = tf_conv3d.depthwise_conv3d_concat(a, b, w, idx, cnt, filt)
     assert torch.equal(out, tf_conv3d.depthwise_conv3d(torch.cat((a, b), 2), w, idx, cnt, filt))
+
+
+def test_max_pool_with_skip_sums_both_gradients_in_the_pooling_kernel(dev):
+    from sph3d_gcn_amd import tf_pool3d, _lib
+    B, N, M, C, K = 3, 900, 300, 128, 32
+    rng = np.random.RandomState(4)
+    xyz = _t(rng.rand(B, N, 3).astype(np.float32), dev)
+    q = xyz[:, :M].contiguous()
+    idx, cnt, dst = tf_nnquery.build_sphere_neighbor(xyz, q, 0.2, None, K)
+    x = rng.randn(B, N, C).astype(np.float32)
+    go, gs = _t(rng.randn(B, M, C).astype(np.float32), dev), _t(rng.randn(B, N, C).astype(np.float32), dev)
+    res = {}
+    for mode in ("fused", "fused_no_transpose", "separate"):
+        _tgraph.clear()
+        if mode != "fused_no_transpose":
+            _tgraph.transpose(idx, cnt, N)
+        xin = _t(x, dev).requires_grad_(True)
+        if mode == "separate":
+            pooled, _ = tf_pool3d.max_pool3d(xin, idx, cnt)
+            skip = xin
+        else:
+            pooled, _, skip = tf_pool3d.max_pool3d_with_skip(xin, idx, cnt)
+        _lib.timing_start()
+        try:
+            ((pooled * go).sum() + (skip * gs).sum()).backward()
+        finally:
+            names = [c[0] for c in _lib.timing_stop()]
+        res[mode] = (_n(xin.grad), _n(pooled), names)
+    assert res["fused"][2].count("sph3d_max_pool3d_grad_t") == 1 and "sph3d_max_pool3d_grad" in res["fused_no_transpose"][2]
+    for mode in ("fused", "fused_no_transpose"):
+        np.testing.assert_array_equal(res[mode][1], res["separate"][1])
+        np.testing.assert_allclose(res[mode][0], res["separate"][0], **TOL)
