@@ -64,11 +64,14 @@ def get_model(points, num_cls, is_training, config=None, graphs=None, points_rea
                                       g["filt_idx"], 'conv' + str(l + 1), config.multiplier[l], reuse=reuse,
                                       weight_decay=config.weight_decay, with_bn=config.with_bn,
                                       with_bias=config.with_bias, is_training=is_training)
-        encoder.append(net)
         if config.num_sample[l] > 1:
             g = plan.pool(l)
-            net = s3g_util.pool3d(net, g["inter_idx"], g["inter_cnt"], method=config.pool_method,
-                                  scope='pool' + str(l + 1))
+            # the level's features go to the pooling and, as the skip connection, to the decoder (as in s3dis_net)
+            net, skip = s3g_util.pool3d_with_skip(net, g["inter_idx"], g["inter_cnt"], method=config.pool_method,
+                                                  scope='pool' + str(l + 1))
+            encoder.append(skip)
+        else:
+            encoder.append(net)
     channels = list(reversed(config.channels))
     multiplier = list(reversed(config.multiplier))
     encoder.reverse()                      # [level L, ..., level 1, mlp1]
@@ -80,7 +83,9 @@ def get_model(points, num_cls, is_training, config=None, graphs=None, points_rea
                                       with_bias=config.with_bias, is_training=is_training)
         net = s3g_util.unpool3d(net, g["inter_idx"], g["inter_cnt"], g["inter_dst"], method=config.unpool_method,
                                 scope='unpool' + str(l + 1))
-        net = torch.cat((net, encoder[l]), dim=2)
+        # tf.concat((net, encoder[l]), axis=2): the next level's separable convolution takes the pair (s3dis_net); the last
+        # concatenation feeds a pointwise layer and is materialised
+        net = (net, encoder[l]) if l + 1 < len(channels) else torch.cat((net, encoder[l]), dim=2)
     net = s3g_util.pointwise_conv3d(net, config.mlp, 'mlp2', weight_decay=config.weight_decay,
                                     with_bn=config.with_bn, with_bias=config.with_bias, reuse=reuse,
                                     is_training=is_training)
