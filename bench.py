@@ -35,6 +35,7 @@ import torch
 import torch.distributed as dist
 
 from sph3d_gcn_amd import _lib
+from sph3d_gcn_amd.harness import optim as hoptim
 from sph3d_gcn_amd.harness import dist as hdist
 from sph3d_gcn_amd.harness import s3dis_net, synth
 
@@ -372,7 +373,7 @@ def main():
     flat = hdist.FlatGradAllReduce(model.parameters())
     flat.broadcast_params(0)
     # train_s3dis.py:224 (epsilon=1e-4); one fused kernel over the flat parameter buffer instead of the foreach chain
-    opt = torch.optim.Adam([flat.flat_param], lr=1e-3, eps=1e-4, fused=True)
+    opt = hoptim.FlatAdam(flat.flat_param, lr=1e-3, eps=1e-4)        # one streaming kernel, torch.optim.Adam's arithmetic
     nparams = flat.flat_param.numel()
 
     # (launch mode: eager on three HIP streams.  A HIP-graph replay of the whole step does capture once every autograd node lives

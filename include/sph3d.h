@@ -396,6 +396,11 @@ int sph3d_depthwise_conv3d_grad_t_cat(int B, int N, int M, int F, int Ca, int Cb
                                       float* grad_b, float* grad_filter, void* workspace, size_t workspace_bytes,
                                       sph3d_stream_t stream);
 
+/* ---- the training loop's optimiser update (train_s3dis.py:224, tf.train.AdamOptimizer) over flat fp32 buffers: one streaming
+ * pass, torch.optim.Adam's arithmetic (no amsgrad / weight decay); step = 1, 2, ... (bias corrections are computed on the host) */
+int sph3d_adam_step(long long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                    float beta2, float eps, int step, sph3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,7 @@ SIGNATURES = {
     "sph3d_elu_bn_workspace": (_S, [_I] * 2),
     "sph3d_pointwise_gemm_bnstats_blocks": (_I, [_I] * 3),
     "sph3d_pointwise_gemm_bnstats": (_I, [_I] * 3 + [_P] * 6),
+    "sph3d_adam_step": (_I, [ctypes.c_longlong] + [_P] * 4 + [_F] * 4 + [_I, _P]),
     "sph3d_pointwise_gemm_skinny_supported": (_I, [_I] * 4),
     "sph3d_pointwise_gemm_skinny": (_I, [_I] * 4 + [_P] * 6),
     "sph3d_pointwise_gemm_skinny_tn_workspace": (_S, [_I] * 4),

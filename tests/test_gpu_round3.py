@@ -729,3 +729,18 @@ def test_max_pool_with_skip_sums_both_gradients_in_the_pooling_kernel(dev):
     for mode in ("fused", "fused_no_transpose"):
         np.testing.assert_array_equal(res[mode][1], res["separate"][1])
         np.testing.assert_allclose(res[mode][0], res["separate"][0], **TOL)
+
+
+@pytest.mark.parametrize("n", [3_935_693, 1024, 7])
+def test_flat_adam_kernel_equals_torch_adam(dev, n):
+    from sph3d_gcn_amd.harness import optim
+    g = torch.Generator(device="cpu").manual_seed(n)
+    p0 = torch.randn(n, generator=g).to(dev)
+    pa = torch.nn.Parameter(p0.clone()); pb = torch.nn.Parameter(p0.clone())
+    oa = optim.FlatAdam(pa, lr=1e-3, eps=1e-4)
+    ob = torch.optim.Adam([pb], lr=1e-3, eps=1e-4)
+    for it in range(5):
+        gr = torch.randn(n, generator=g).to(dev) * (0.1 if it != 2 else 0.0)      # one all-zero gradient step
+        pa.grad = gr.clone(); pb.grad = gr.clone()
+        oa.step(); ob.step()
+    np.testing.assert_allclose(_n(pa), _n(pb), rtol=2e-6, atol=2e-7)
