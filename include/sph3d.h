@@ -262,43 +262,40 @@ int sph3d_farthest_point_sample(int b, int n, int m, const float* inp, int* out,
 int sph3d_gather_nd(int B, int N, long long S, int row, const int* pairs, const void* params, void* out,
                     sph3d_stream_t stream);
 
-/* ---- LDS-tiled depthwise convolution (tile.hip, convtile.hip) ---------------------------------------
- * Same results as sph3d_depthwise_conv3d (tf_ops/convolution/tf_conv3d_gpu.cu:7-29), for callers that keep a graph
- * across calls: a per-graph TILE PLAN lets the kernels stage
- * the union of the neighbour rows of 16 spatially consecutive points in LDS once and gather from LDS, with the
- * edges of a point grouped by bin (rows of a bin are summed first, multiplied by the filter row once).
- * Plan of one graph, all device arrays provided by the caller:
+/* ---- depthwise convolution gathered from LDS tiles (csrc/convlds.hip) -------------------------------
+ * Same results, bit for bit, as sph3d_depthwise_conv3d (replaces depthwise_conv3d_forward,
+ * tf_ops/convolution/tf_conv3d_gpu.cu:7-29): the neighbour rows of a tile of <= 32 spatially consecutive output
+ * points are staged in LDS once (LDS-DMA) and every edge is one LDS read instead of one L2 -> L1 row gather.
+ * A per-graph PLAN (shared by every convolution and channel slice on the graph), all device arrays from the caller:
  *   sph3d_spatial_order   order[B,N]: a permutation of each cloud in which consecutive points are close (Morton
- *                         cells); any permutation is valid, a random one only loses the row reuse;
- *   sph3d_rows_by_bin     forward graph as a binned CSR: bounds[B*M*(F+1)] (first entry of bin f of point m, then
- *                         the end), key[B*M*K] neighbour ids sorted by bin inside each point's K-entry slab;
- *                         needs K <= 64, F <= 63;
- *   sph3d_tile_plan       T targets and NS source rows per cloud, bounds / key from sph3d_rows_by_bin.  ucap = rows a
- *                         tile may stage (multiple of 4, <= 252; >= K).  F <= 62.  Outputs, all at addresses
- *                         computed from the tile index cand = b*ceil(T/16) + c, so that a kernel can fetch a tile's
- *                         data two tiles ahead: tile_hdr[cand*2] = {targets, rows} of the tile's first sub-tile;
- *                         tile_rows[cand*ucap + i] its row list; tile_targets[cand*16 + i] the tile's targets;
- *                         tile_pb[(cand*16+i)*(F+2)]: first slot word of each bin of target i, end, edge count;
- *                         slot_words[(cand*16+i)*64 + j]: per (target, bin) group the LDS slots of its rows, one byte
- *                         each, padded to whole words.  Further sub-tiles of a tile whose union did not fit go to
- *                         extra_steps[b] (8 ints each; counters[1+b] of them), their row lists behind the fixed part
- *                         of tile_rows.  Sizes from sph3d_tile_plan_sizes (E = B*M*K).
- * The tiled kernel covers C >= 128 (128-channel row slices), r in {1,2}, F*128*r*4 + (ucap+2)*512 B <= 160 KiB. */
+ *                         cells); any permutation (or NULL = index order) is valid, a random one only loses row reuse;
+ *   sph3d_conv_plan       nn_index / nn_count / bin_index [B,M,K] of the graph (K <= 64, N <= 65536 source rows,
+ *                         F <= 65 bins; out-of-range ids / bins are clamped like the gather kernels do).  Per chunk of
+ *                         64 consecutive positions of `order` (c = b*ceil(M/64) + chunk):
+ *                           chunk_hdr[c*132]        tiles of the chunk; per tile t: [1+2t] = first | targets << 8 | rows << 16,
+ *                                                   [2+2t] = offset of its row list in the chunk's slab
+ *                           records[(c*64 + p)*32]  per target 64 u16 entries in neighbour order:
+ *                                                   LDS slot of the edge's row | bin << 8 (padding: zero row, zero filter row);
+ *                                                   a tile's targets are contiguous from `first`, most neighbours first
+ *                           target_meta[c*64 + p]   target id | neighbour count << 24
+ *                           row_lists[c*4096 ...]   the tiles' source-row ids (u16), ascending per tile
+ *                         sizes from sph3d_conv_plan_sizes; sph3d_conv_plan_ucap(F) = rows a tile stages (0: F unsupported).
+ * The kernel covers r in {1,2}, C a multiple of 64 (64-channel slices: 256-B rows), K <= 64; _cat reads the channel
+ * concatenation [input_a (Ca) | input_b (Cb)] in place (Ca, Cb multiples of 64). */
 int sph3d_spatial_order(int B, int N, const float* xyz, int* order, sph3d_stream_t stream);
-int sph3d_rows_by_bin(int B, int M, int K, int F, const int* nn_index, const int* nn_count, const int* bin_index,
-                      int* bounds, int* key, sph3d_stream_t stream);
-int sph3d_tile_plan_sizes(int B, int T, int F, int ucap, long long E, int* n_cands, size_t* hdr_ints, size_t* tgt_ints,
-                          size_t* rows_ints, size_t* pb_ints, size_t* slot_words, size_t* xstep_ints, size_t* counter_ints);
-int sph3d_tile_plan(int B, int T, int NS, int F, int ucap,
-                    const int* order, const int* bounds, const int* key,
-                    int* tile_hdr, int* tile_targets, int* tile_rows, int* tile_pb,
-                    int* slot_words, int* extra_steps, int* counters, sph3d_stream_t stream);
-int sph3d_depthwise_conv3d_tiled_supported(int F, int C, int r, int K, int ucap);   /* 1 if the tiled kernel applies */
-int sph3d_depthwise_conv3d_tiled(int B, int N, int M, int F, int C, int r, int ucap,
-                                 const int* tile_hdr, const int* tile_targets, const int* tile_rows,
-                                 const int* tile_pb, const int* slot_words, const int* extra_steps,
-                                 const int* counters,
-                                 const float* input, const float* filter, float* output, sph3d_stream_t stream);
+int sph3d_conv_plan_ucap(int F);
+int sph3d_conv_plan_sizes(int B, int M, size_t* hdr_ints, size_t* rec_words, size_t* meta_ints, size_t* rowlist_shorts);
+int sph3d_conv_plan(int B, int N, int M, int K, int F, const int* order, const int* nn_index, const int* nn_count,
+                    const int* bin_index, int* chunk_hdr, unsigned* records, int* target_meta,
+                    unsigned short* row_lists, sph3d_stream_t stream);
+int sph3d_depthwise_conv3d_lds_supported(int F, int C, int r, int K);   /* 1 if the LDS kernel applies */
+int sph3d_depthwise_conv3d_lds(int B, int N, int M, int F, int C, int r, const int* chunk_hdr, const unsigned* records,
+                               const int* target_meta, const unsigned short* row_lists, const float* input,
+                               const float* filter, float* output, sph3d_stream_t stream);
+int sph3d_depthwise_conv3d_lds_cat(int B, int N, int M, int F, int Ca, int Cb, int r, const int* chunk_hdr,
+                                   const unsigned* records, const int* target_meta, const unsigned short* row_lists,
+                                   const float* input_a, const float* input_b, const float* filter, float* output,
+                                   sph3d_stream_t stream);
 
 /* ---- pointwise 1x1 feature GEMM (fp32 MFMA) -----------------------------
  * replaces the tf.matmul inside separable_conv3d / pointwise_conv3d /

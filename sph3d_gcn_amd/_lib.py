@@ -51,11 +51,12 @@ SIGNATURES = {
     "sph3d_depthwise_conv3d_cat": (_I, [_I] * 8 + [_P] * 8),
     "sph3d_depthwise_conv3d_grad_t_cat": (_I, [_I] * 7 + [_P] * 12 + [_P, _S, _P]),
     "sph3d_spatial_order": (_I, [_I, _I, _P, _P, _P]),
-    "sph3d_rows_by_bin": (_I, [_I] * 4 + [_P] * 6),
-    "sph3d_tile_plan_sizes": (_I, [_I, _I, _I, _I, ctypes.c_longlong] + [_P] * 8),
-    "sph3d_tile_plan": (_I, [_I] * 5 + [_P] * 11),
-    "sph3d_depthwise_conv3d_tiled_supported": (_I, [_I] * 5),
-    "sph3d_depthwise_conv3d_tiled": (_I, [_I] * 7 + [_P] * 11),
+    "sph3d_conv_plan_ucap": (_I, [_I]),
+    "sph3d_conv_plan_sizes": (_I, [_I, _I] + [_P] * 4),
+    "sph3d_conv_plan": (_I, [_I] * 5 + [_P] * 9),
+    "sph3d_depthwise_conv3d_lds_supported": (_I, [_I] * 4),
+    "sph3d_depthwise_conv3d_lds": (_I, [_I] * 6 + [_P] * 8),
+    "sph3d_depthwise_conv3d_lds_cat": (_I, [_I] * 7 + [_P] * 9),
     "sph3d_scatter_grad_t": (_I, [_I] * 4 + [_P] * 6),
     "sph3d_scatter_grad_workspace": (_S, [_I] * 4),
     "sph3d_mean_interpolate": (_I, [_I] * 5 + [_P] * 5),
@@ -137,7 +138,7 @@ def timing_stop():
     return out
 
 
-_NO_TIME = ("sph3d_abi_version", "sph3d_last_error", "sph3d_build_info", "workspace", "_blocks", "_supported")
+_NO_TIME = ("sph3d_abi_version", "sph3d_last_error", "sph3d_build_info", "workspace", "_blocks", "_supported", "_sizes", "_ucap")
 
 
 class _Proxy:

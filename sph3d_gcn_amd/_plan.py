@@ -1,15 +1,14 @@
-"""Per-graph tile plans of the LDS-tiled depthwise convolution (include/sph3d.h: sph3d_tile_plan).
+"""Per-graph LDS tile plans of the depthwise convolution (include/sph3d.h: sph3d_conv_plan; csrc/convlds.hip).
 
-A plan belongs to a neighbour graph, not to a convolution: every convolution that reuses the graph's tensors shares
-it.  It needs the coordinates of the graph's points (to put spatially close points in one tile); the convolution op
-itself never sees coordinates (tf_ops/convolution/tf_conv3d.py:10-21), so ``tf_buildkernel.spherical_kernel`` — the op
-that produced the bin indices from the coordinates — registers them here, keyed by the identity of its output tensor.
+A plan belongs to a neighbour graph, not to a convolution: every convolution (and every 64-channel slice of it) that
+reuses the graph's tensors shares it.  It groups the graph's output points into tiles of <= 32 spatially consecutive
+points whose neighbour rows fit the LDS; "spatially consecutive" needs the points' coordinates, which the convolution
+op never sees (tf_ops/convolution/tf_conv3d.py:10-21) — so the ops that produce the bin indices from the coordinates
+(``tf_buildkernel.spherical_kernel``, ``tf_nnquery.build_sphere_graph``) register them here, keyed by the identity of
+their output tensor.  Without coordinates the plan uses index order (correct, less reuse per tile).
 
-Measured trade-off (round 2, MI355X, B = 16 x 8192 points): the tiled forward kernel runs a C = 128 layer in 0.207 ms
-against 0.275 ms for the gather kernel, but a plan costs 0.32 ms per level-0 graph.  A training step builds new graphs
-every step and uses each for two forward convolutions, so the default mode is ``"gather"``; ``set_mode("tiled")`` is for
-callers that keep a graph (inference on a fixed cloud, many steps on one batch) and for the tests / tools.  Results are
-the same either way up to fp32 summation order.
+Results do not depend on the plan: the kernel sums a point's neighbours in neighbour order with the gather kernel's
+arithmetic, so ``"lds"`` and ``"gather"`` modes produce the same bits.
 
 Entries hold strong references to the tensors they were built from (so a data_ptr cannot be recycled for another
 graph while its entry lives) and an event for consumers on other streams, like ``_tgraph``.
@@ -21,17 +20,16 @@ import torch
 
 from . import _lib
 
-UCAP = 236            # rows a tile stages: (UCAP + 2) * 512 B of rows + the 33-KB filter of 33 bins x 256 outputs fit 160 KB of LDS
 MIN_POINTS = 64       # below this a level is a handful of tiles: the gather kernels are used
-_MAX_ENTRIES = 16
+_MAX_ENTRIES = 24
 
-_mode = "gather"      # "gather" | "tiled": which forward kernel a convolution with a registered graph geometry uses
+_mode = "gather"      # "gather" | "lds": which forward kernel a covered convolution uses
 
 
 def set_mode(mode):
     global _mode
-    if mode not in ("gather", "tiled"):
-        raise ValueError("mode must be 'gather' or 'tiled'")
+    if mode not in ("gather", "lds"):
+        raise ValueError("mode must be 'gather' or 'lds'")
     _mode = mode
 
 
@@ -43,13 +41,13 @@ def _ident(t):
     return (0, 0) if t is None else (t.data_ptr(), t._version)
 
 
-_geom = collections.OrderedDict()      # ident(bin_index) -> (database_xyz, query_xyz, bin_index)
+_geom = collections.OrderedDict()      # ident(bin_index) -> (query_xyz, bin_index)
 _orders = collections.OrderedDict()    # ident(xyz) -> entry
-_fwd = collections.OrderedDict()
+_plans = collections.OrderedDict()
 
 
 def clear():
-    for d in (_geom, _orders, _fwd):
+    for d in (_geom, _orders, _plans):
         d.clear()
 
 
@@ -59,28 +57,30 @@ def _trim(d, n=_MAX_ENTRIES):
 
 
 def register_geometry(bin_index, database, query):
-    """called by tf_buildkernel.spherical_kernel: bin_index was computed from these coordinates"""
-    _geom[_ident(bin_index)] = (database, query, bin_index)
+    """called by the binning ops: bin_index was computed for these query coordinates"""
+    _geom[_ident(bin_index)] = (query, bin_index)
     _trim(_geom, 2 * _MAX_ENTRIES)
 
 
 def _entry(table, key, build, keep):
     """cached build with cross-stream ordering: -> tuple of tensors"""
-    cur = torch.cuda.current_stream()
+    cur_raw = _lib.current_raw_stream()
     hit = table.get(key)
     if hit is not None:
         table.move_to_end(key)
-        out, _keep, ev, built_on = hit
-        if built_on != cur.cuda_stream:
+        out, _keep, ev, synced = hit
+        if cur_raw not in synced:                # built ahead of time on the graph stream: order this stream after it, ONCE
+            cur = torch.cuda.current_stream()
             cur.wait_event(ev)
             for t in out:
                 if torch.is_tensor(t):
                     t.record_stream(cur)
+            synced.add(cur_raw)
         return out
     out = build()
     ev = torch.cuda.Event()
-    ev.record(cur)
-    table[key] = (out, keep, ev, cur.cuda_stream)
+    ev.record(torch.cuda.current_stream())
+    table[key] = (out, keep, ev, {cur_raw})
     _trim(table)
     return out
 
@@ -96,44 +96,38 @@ def spatial_order(xyz):
     return _entry(_orders, (_ident(xyz), tuple(xyz.shape)), build, (xyz,))[0]
 
 
-def applies(N, M, K, F, C, r, ucap=None):
-    """does the tiled forward kernel cover this layer (and is the mode on)?"""
-    ucap = UCAP if ucap is None else int(ucap)
-    return (_mode == "tiled" and K <= 64 and min(N, M) >= MIN_POINTS
-            and bool(_lib.lib().sph3d_depthwise_conv3d_tiled_supported(F, C, r, K, ucap)))
+def applies(N, M, K, F, C, r):
+    """does the LDS kernel cover this layer (and is the mode on)?"""
+    return (_mode == "lds" and min(N, M) >= MIN_POINTS and N <= 65536
+            and bool(_lib.lib().sph3d_depthwise_conv3d_lds_supported(F, C, r, K)))
 
 
-def forward_plan(nn_index, nn_count, bin_index, F, ucap=None):
-    """-> (hdr, targets, rows, pb, slotw, xsteps, counters, bounds, key, ucap) (see include/sph3d.h: sph3d_tile_plan), or
-    None when nobody registered the coordinates of this graph"""
-    g = _geom.get(_ident(bin_index))
-    if g is None:
-        return None
-    query = g[1]
-    ucap = UCAP if ucap is None else int(ucap)
+def conv_plan(nn_index, nn_count, bin_index, F, n_src):
+    """-> (chunk_hdr, records, target_meta, row_lists) of the graph (include/sph3d.h: sph3d_conv_plan)"""
     B, M, K = nn_index.shape
-    if query.shape[1] != M:
-        return None
 
     def build():
         dev = nn_index.device
         l = _lib.lib()
-        order = spatial_order(query)
-        bounds = torch.empty((B * M * (F + 1),), dtype=torch.int32, device=dev)
-        key = torch.empty((B * M * K + 64,), dtype=torch.int32, device=dev)
-        _lib.check(l.sph3d_rows_by_bin(B, M, K, F, _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(bin_index),
-                                       _lib.ptr(bounds), _lib.ptr(key), _lib.stream_ptr()))
-        N = g[0].shape[1]
-        n_c = ctypes.c_int()
-        sz = [ctypes.c_size_t() for _ in range(7)]
-        _lib.check(l.sph3d_tile_plan_sizes(B, M, F, ucap, ctypes.c_longlong(B * M * K), ctypes.byref(n_c),
-                                           *[ctypes.byref(x) for x in sz]))
-        hdr, tgt, rows, pb, slotw, xsteps, counters = (torch.empty((x.value,), dtype=torch.int32, device=dev) for x in sz)
-        _lib.check(l.sph3d_tile_plan(B, M, N, F, ucap, _lib.ptr(order), _lib.ptr(bounds), _lib.ptr(key), _lib.ptr(hdr),
-                                     _lib.ptr(tgt), _lib.ptr(rows), _lib.ptr(pb), _lib.ptr(slotw), _lib.ptr(xsteps),
-                                     _lib.ptr(counters), _lib.stream_ptr()))
-        return (hdr, tgt, rows, pb, slotw, xsteps, counters, bounds, key, ucap)
+        g = _geom.get(_ident(bin_index))
+        order = spatial_order(g[0]) if (g is not None and g[0].shape[1] == M) else None
+        sz = [ctypes.c_size_t() for _ in range(4)]
+        _lib.check(l.sph3d_conv_plan_sizes(B, M, *[ctypes.byref(x) for x in sz]))
+        hdr = torch.empty((sz[0].value,), dtype=torch.int32, device=dev)
+        rec = torch.empty((sz[1].value,), dtype=torch.int32, device=dev)
+        meta = torch.empty((sz[2].value,), dtype=torch.int32, device=dev)
+        rows = torch.empty((sz[3].value,), dtype=torch.int16, device=dev)
+        _lib.check(l.sph3d_conv_plan(B, int(n_src), M, K, F, _lib.ptr(order), _lib.ptr(nn_index), _lib.ptr(nn_count),
+                                     _lib.ptr(bin_index), _lib.ptr(hdr), _lib.ptr(rec), _lib.ptr(meta), _lib.ptr(rows),
+                                     _lib.stream_ptr()))
+        return (hdr, rec, meta, rows)
 
-    k = (_ident(nn_index), _ident(nn_count), _ident(bin_index), F, tuple(nn_index.shape), ucap)
-    return _entry(_fwd, k, build, (nn_index, nn_count, bin_index))
+    k = (_ident(nn_index), _ident(nn_count), _ident(bin_index), int(F), int(n_src), tuple(nn_index.shape))
+    return _entry(_plans, k, build, (nn_index, nn_count, bin_index))
 
+
+def prebuild(nn_index, nn_count, bin_index, F, n_src):
+    """build the plan now, on the caller's (graph) stream, if a convolution on this graph could use it"""
+    B, M, K = nn_index.shape
+    if _mode == "lds" and K <= 64 and min(n_src, M) >= MIN_POINTS and n_src <= 65536 and _lib.lib().sph3d_conv_plan_ucap(F) > 0:
+        conv_plan(nn_index, nn_count, bin_index, F, n_src)

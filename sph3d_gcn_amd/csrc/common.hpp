@@ -11,10 +11,6 @@ constexpr int kWave = 64;           // CDNA wavefront width
 constexpr int kRefGrid = 32;        // the reference launches every kernel <<<32,1024>>>;
 constexpr int kRefBlock = 1024;     // its thread->work mapping defines the radius-growth chains and FPS tie-break
 
-// tile plans (tile.hip -> convtile.hip): targets per candidate tile, ints per tile descriptor
-constexpr int kTileP = 16;
-constexpr int kSlotWords = 64;     // slot words (4 byte-sized LDS slots each) a light target may have: one wave register
-
 // ---- host-side status plumbing ------------------------------------------------
 void set_error(const char* fmt, ...);   // stores a thread-local message (api.cpp)
 

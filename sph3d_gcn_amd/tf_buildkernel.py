@@ -45,7 +45,7 @@ def _spherical_kernel_impl(database: torch.Tensor, query: torch.Tensor, nn_index
         B, N, M, K, n_azim, p_elev, q_radi, radius, _lib.ptr(database), _lib.ptr(query),
         _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(nn_dist), _lib.ptr(filt_index), _lib.stream_ptr()))
     # the convolutions that will use these bins can tile their work spatially: remember which coordinates they came from
-    # (only when a tiled mode is on: the registry pins the tensors)
+    # (only when the LDS mode is on: the registry pins the tensors)
     if _plan.get_mode() != "gather":
         _plan.register_geometry(filt_index, database, query)
     return filt_index

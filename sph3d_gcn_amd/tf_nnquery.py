@@ -152,7 +152,9 @@ def build_sphere_graph(xyz, radius, nnsample, kernel, with_transpose=True):
     _lib.check(fn(B, N, N, K, float(radius), n, p, q, _lib.ptr(xyz), _lib.ptr(xyz), _lib.ptr(nn_index),
                   _lib.ptr(nn_count), _lib.ptr(nn_dist), _lib.ptr(filt), _lib.ptr(ws), wsb, _lib.stream_ptr()))
     if _plan.get_mode() != "gather":
+        # the convolutions on this graph gather from LDS tiles: their plan is built here, on the graph stream
         _plan.register_geometry(filt, xyz, xyz)
+        _plan.prebuild(nn_index, nn_count, filt, F, N)
     if with_transpose:
         _tgraph.transpose(nn_index, nn_count, N, bin_index=filt, num_bins=F, counted_workspace=ws)
     return nn_index, nn_count, nn_dist, filt
