@@ -492,15 +492,16 @@ def main():
                 conv_gather["isolated_us"] = round(iso * 1e6, 1)
                 conv_gather["isolated_frac"] = round(ab / 1e9 / iso / HBM_PEAK_GBS, 4)
             from sph3d_gcn_amd import _plan
-            _plan.set_mode("tiled")              # the LDS-tiled kernel of the same layer (opt-in: its plan costs 0.3 ms per graph)
-            try:
+            prev_mode = _plan.get_mode()
+            _plan.set_mode("lds")                # the LDS-tile kernel of the same layer (csrc/convlds.hip; opt-in: its per-graph
+            try:                                 # plan costs more graph-stream time than it saves on the feature path)
                 iso_t = isolated_call_seconds(name, ints, dev)
             finally:
-                _plan.set_mode("gather")
+                _plan.set_mode(prev_mode)
                 _plan.clear()
             if iso_t:
-                conv_gather["tiled_kernel_isolated_us"] = round(iso_t * 1e6, 1)
-                conv_gather["tiled_kernel_isolated_frac"] = round(ab / 1e9 / iso_t / HBM_PEAK_GBS, 4)
+                conv_gather["lds_kernel_isolated_us"] = round(iso_t * 1e6, 1)
+                conv_gather["lds_kernel_isolated_frac"] = round(ab / 1e9 / iso_t / HBM_PEAK_GBS, 4)
     sph3d_ms = sum(v[0] for v in per.values()) / ev_steps
 
     if is_rank0:

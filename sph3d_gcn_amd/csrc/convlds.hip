@@ -1,8 +1,8 @@
 // convlds.hip — depthwise spherical convolution gathered from LDS tiles (forward), gfx950.
 //
-// Same arithmetic, same summation order (k = 0..cnt-1, one fmaf per edge and output, one reciprocal per point) and
-// therefore the same bits as dwconv_fwd_multi of conv3d.hip; replaces depthwise_conv3d_forward
-// (tf_ops/convolution/tf_conv3d_gpu.cu:7-29).  What changes is where the neighbour rows come from.
+// Replaces depthwise_conv3d_forward (tf_ops/convolution/tf_conv3d_gpu.cu:7-29): out = 1/cnt * sum_k in[nn_k] * filt[bin_k], fp32,
+// summed bin group by bin group ((x_a + x_b) * w per pair of edges of a bin; the reference: edge by edge in neighbour order):
+// ~1e-7 relative to the oracle, bound 1e-5.  What changes against the gather kernels of conv3d.hip is where the rows come from.
 //
 // Why.  The gather kernels fetch one feature row per edge through the CU's vector L1: 6.3 M edges x 512 B = 3.2 GB at
 // level 0 of the S3DIS plan, served L2 -> L1 at <= 25 TB/s (tools/micro/gather_bw.hip): 129 us before a single FMA, 196 us
@@ -18,17 +18,19 @@
 //   * a channel SLICE is 64 input channels = 256-B rows; a lane owns 4 input channels (one ds_read_b128 per edge) and their
 //     4r outputs, so a target needs 16 lanes and a wave carries FOUR targets in lockstep (targets of a tile are dealt to
 //     waves in order of neighbour count, so the four of a wave finish together);
-//   * per target the plan holds a RECORD of 64 u16 entries in neighbour order, entry = LDS slot of the edge's row | bin << 8
-//     (padding entries: the zero row and the zero filter row).  Records of a tile travel to LDS with the rows; a lane reads 8
-//     entries with one ds_read_b128 and turns an entry into the row address AND the filter address with one v_perm_b32 each
-//     ((slot << 8) | lane byte, (bin << 8) | lane byte: rows and filter planes are 256 B apart by construction, region bases
-//     are immediate offsets of the ds_read);
-//   * per edge and wave: 2 v_perm + 1 row read + r filter reads + 2r packed FMAs, nothing else; eight edges are unrolled;
+//   * per target the plan holds a RECORD: its edges sorted by bin and PAIRED inside a bin group (an odd group's last edge
+//     pairs with an all-zero LDS row), 48 pair entries {slot A | slot B << 16, bin}.  Records of a tile travel to LDS with
+//     the rows; a lane reads 4 entries with two ds_read_b128 and turns an entry into two row addresses and the filter address
+//     with one v_perm_b32 each ((slot << 8) | lane byte, (bin << 8) | lane byte: rows and filter planes are 256 B apart by
+//     construction, region bases are immediate offsets of the ds_read);
+//   * per pair and wave: 3 v_perm + 2 row reads + r filter reads + 2 packed adds + 2r packed FMAs, nothing else: the filter
+//     row — two thirds of the LDS bytes of an edge at r = 2 — is read once per pair (measured with tools/micro/lds_fma.hip:
+//     a b128 read costs 2.1 ns per CU and overlaps with the FMAs, so the reads per edge ARE the kernel's floor);
 //   * rows travel global -> LDS by LDS-DMA (global_load_lds_dwordx4), no registers; two 8-wave workgroups per CU (80 KB of
 //     LDS each), so one stages while the other gathers — no software pipeline inside a workgroup.
 // The plan is per GRAPH (every convolution on the graph and its channel slices share it), built by one kernel after the
-// neighbour search: greedy tiles of <= 32 spatially consecutive targets whose row union fits the LDS, union ranks by bitmap +
-// prefix popcounts, records.  Nothing is sorted by bin: the summation order of a target is its neighbour order.
+// neighbour search: greedy tiles of <= 64 spatially consecutive targets whose row union fits the LDS, union ranks by bitmap +
+// prefix popcounts, bin-sorted pair records.
 #include <cstdlib>
 #include "common.hpp"
 
@@ -37,7 +39,8 @@ namespace sph3d {
 constexpr int kLcChunk = 128;           // consecutive positions of the spatial order handled by one plan workgroup; tiles never span chunks
 
 constexpr int kLcHdrInts = 132;         // per chunk: [0] tiles, [1 + 2t] first | targets << 8 | rows << 16, [2 + 2t] row-list offset
-constexpr int kLcRecWords = 64;         // 64 u32 entries per target: slot | bin << 16
+constexpr int kLcPairs = 48;            // pair entries per target: <= (64 edges + 32 odd bin groups) / 2
+constexpr int kLcRecWords = 2 * kLcPairs;   // a pair entry = two words: slot A | slot B << 16, bin
 constexpr int kLcRowBytes = 256;        // one 64-channel slice of a feature row
 constexpr int kLcRowsPerChunk = kLcChunk * 64;
 
@@ -175,13 +178,14 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(int N, int bpa, con
 //   2. wave 0 walks the targets once and cuts tiles greedily: a tile takes consecutive targets while the union of
 //      their source rows fits `ucap` and it has < maxT targets (an LDS bitmap of the cloud tells new rows from known ones);
 //   3. one wave per tile: bitmap of the tile's rows -> exclusive prefix popcounts -> rank of a row = its LDS slot;
-//      row list (ascending row id); targets ranked by neighbour count (descending, ties by position);
-//      per target the record of 64 entries (slot | bin << 16 in neighbour order, padding = ucap | F << 16) and
-//      meta = target id | count << 24.
+//      row list (ascending row id); per target the RECORD: its edges sorted by bin and paired inside a bin group, 48 pair
+//      entries {slot A | slot B << 16, bin} (an odd group's last edge pairs with the zero row = slot ucap; unused entries:
+//      zero row twice and the zero filter row F) and meta = {target id, count | pairs << 8}; targets ranked by pair count
+//      (descending, ties by position).
 // Outputs (all addressed from the chunk index):
 //   chdr    [B*nchunks][132]     int : see kLcHdrInts
-//   rec     [B*nchunks*128][64]  u32 : records, a tile's targets contiguous from `first`, in rank order
-//   tmeta   [B*nchunks*128]      int
+//   rec     [B*nchunks*128][96]  u32 : records, a tile's targets contiguous from `first`, in rank order
+//   tmeta   [B*nchunks*128][2]   int
 //   rowlist [B*nchunks][128*64]  u16 : the tiles' row lists one after the other
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lc_plan_kernel(
@@ -196,6 +200,7 @@ __global__ __launch_bounds__(256) void lc_plan_kernel(
     __shared__ int sTm[kLcChunk], sCnt[kLcChunk];
     __shared__ int sTile[kLcChunk];                   // first | targets << 8
     __shared__ int sNt;
+    __shared__ unsigned short sPair[4][kLcPairs * 4]; // per wave: the record under construction
     const int tid = (int)threadIdx.x;
     const int wave = uniform(tid >> 6);
     const int lane = lane_id();
@@ -318,25 +323,69 @@ __global__ __launch_bounds__(256) void lc_plan_kernel(
             hp[1 + 2 * t] = tstart | (T << 8) | (U << 16);
             hp[2 + 2 * t] = uoff;
         }
-        // rank of target tstart + lane among the tile's targets: more neighbours first, ties by position
-        const int myc = lane < T ? sCnt[tstart + lane] : -1;
+        // a target's edges are sorted by bin and PAIRED inside a bin group (an odd group's last edge pairs with the zero
+        // row): the consumer reads one filter row per pair.  Pairs per target: sum over groups of ceil(n / 2) <= 48.
+        // rank of target tstart + lane among the tile's targets: more PAIRS first, ties by position
+        int mypairs = -1;
+        for (int qq = 0; qq < T; qq++) {
+            const int q = tstart + qq;
+            const int cq = sCnt[q];
+            const bool valid = lane < cq;
+            const int f = sBin[q][lane];
+            unsigned long long rem = __ballot(valid);
+            int np = 0;
+            while (rem) {
+                const int f0 = __builtin_amdgcn_readlane(f, (int)__builtin_ctzll(rem));
+                const unsigned long long mk = __ballot(valid && f == f0);
+                np += (__popcll(mk) + 1) >> 1;
+                rem &= ~mk;
+            }
+            if (lane == qq) mypairs = np;
+        }
         int rank = 0;
         for (int i = 0; i < T; i++) {
-            const int ci = __builtin_amdgcn_readlane(myc, i);
-            rank += (ci > myc || (ci == myc && i < lane)) ? 1 : 0;
+            const int ci = __builtin_amdgcn_readlane(mypairs, i);
+            rank += (ci > mypairs || (ci == mypairs && i < lane)) ? 1 : 0;
         }
+        unsigned short* sp = sPair[wave];
         for (int qq = 0; qq < T; qq++) {
             const int q = tstart + qq;
             const int cq = sCnt[q];
             const int dst = tstart + __builtin_amdgcn_readlane(rank, qq);
-            unsigned ent = (unsigned)ucap | ((unsigned)F << 16);
-            if (lane < cq) {
+            const bool valid = lane < cq;
+            const int f = sBin[q][lane];
+            int slot = ucap;
+            if (valid) {
                 const int n = sIdx[q][lane];
-                const int slot = (int)preW[n >> 5] + __popc(bmW[n >> 5] & ((1u << (n & 31)) - 1u));
-                ent = (unsigned)slot | ((unsigned)sBin[q][lane] << 16);
+                slot = (int)preW[n >> 5] + __popc(bmW[n >> 5] & ((1u << (n & 31)) - 1u));
             }
-            rec[(chunk * kLcChunk + dst) * kLcRecWords + lane] = ent;
-            if (lane == 0) tmeta[chunk * kLcChunk + dst] = sTm[q] | (cq << 24);
+            // default entries: zero row twice, zero filter row
+            for (int i = lane; i < kLcPairs * 4; i += 64) sp[i] = (unsigned short)((i & 3) < 2 ? ucap : ((i & 3) == 2 ? F : 0));
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            unsigned long long rem = __ballot(valid);
+            int pbase = 0;
+            while (rem) {
+                const int f0 = __builtin_amdgcn_readlane(f, (int)__builtin_ctzll(rem));
+                const unsigned long long mk = __ballot(valid && f == f0);
+                if (valid && f == f0) {
+                    const int i = prefix_popc(mk);
+                    const int pr = pbase + (i >> 1);
+                    sp[pr * 4 + (i & 1)] = (unsigned short)slot;
+                    if ((i & 1) == 0) sp[pr * 4 + 2] = (unsigned short)f0;
+                }
+                pbase += (__popcll(mk) + 1) >> 1;
+                rem &= ~mk;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            unsigned* rp = rec + (chunk * kLcChunk + dst) * kLcRecWords;
+            const unsigned* sw = reinterpret_cast<const unsigned*>(sp);
+            rp[lane] = sw[lane];
+            if (lane < kLcRecWords - 64) rp[64 + lane] = sw[64 + lane];
+            if (lane == 0) {
+                tmeta[(chunk * kLcChunk + dst) * 2] = sTm[q];
+                tmeta[(chunk * kLcChunk + dst) * 2 + 1] = cq | (pbase << 8);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         }
     }
 }
@@ -347,26 +396,35 @@ __global__ __launch_bounds__(256) void lc_plan_kernel(
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef SPH3D_LC_PERM
 #define SPH3D_LC_PERM 1
 #endif
-// entry -> (slot << 8) | lane byte and (bin << 8) | lane byte.  v_perm_b32: selector bytes 0-3 take bytes of the second
-// operand, 4-7 of the first, 0x0c is a zero byte
-__device__ __forceinline__ unsigned lc_arow(unsigned ent, unsigned lb)
+// pair entry {slot A | slot B << 16, bin} -> (slot << 8) | lane byte, (bin << 8) | lane byte.  v_perm_b32: selector bytes
+// 0-3 take bytes of the second operand, 4-7 of the first, 0x0c is a zero byte
+__device__ __forceinline__ unsigned lc_arow_a(unsigned w0, unsigned lb)
 {
 #if SPH3D_LC_PERM
-    return __builtin_amdgcn_perm(ent, lb, 0x0c050400u);
+    return __builtin_amdgcn_perm(w0, lb, 0x0c050400u);
 #else
-    return ((ent & 0xffffu) << 8) | lb;
+    return ((w0 & 0xffffu) << 8) | lb;
 #endif
 }
-__device__ __forceinline__ unsigned lc_afil(unsigned ent, unsigned lb)
+__device__ __forceinline__ unsigned lc_arow_b(unsigned w0, unsigned lb)
 {
 #if SPH3D_LC_PERM
-    return __builtin_amdgcn_perm(ent, lb, 0x0c0c0600u);
+    return __builtin_amdgcn_perm(w0, lb, 0x0c070600u);
 #else
-    return (((ent >> 16) & 0xffu) << 8) | lb;
+    return ((w0 >> 16) << 8) | lb;
+#endif
+}
+__device__ __forceinline__ unsigned lc_afil(unsigned w1, unsigned lb)
+{
+#if SPH3D_LC_PERM
+    return __builtin_amdgcn_perm(w1, lb, 0x0c0c0400u);
+#else
+    return ((w1 & 0xffu) << 8) | lb;
 #endif
 }
 
@@ -388,8 +446,13 @@ __device__ __forceinline__ T lc_ld(unsigned addr)
     return *reinterpret_cast<const __attribute__((address_space(3))) T*>((size_t)addr);
 }
 
+// workgroup barrier WITHOUT the release fence of __syncthreads(): that fence waits for the wave's global stores (vmcnt(0)), i.e.
+// every tile's output rows would have to reach the L2 before its LDS rows may be replaced (measured: 4000 of 14700 cycles per
+// tile).  Only LDS traffic is ordered here: the wave's own LDS operations are complete, then the barrier.
+__device__ __forceinline__ void lc_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct LcTile {
-    int valid, b, chunk, a, uoff;
+    int valid, b, chunk, slice, a, uoff;
 };
 
 // R = depth multiplier, PR = filter rows per LDS plane (>= F + 1), NW = waves per workgroup.  The input may be the channel
@@ -411,54 +474,41 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
     const int l16 = lane & 15;
     const int CR = C * R;
 
-    // ---- this workgroup's slice and its share of the chunks: the workgroups of an XCD walk the XCD's clouds one after the
-    // other (every part takes its range of chunks of cloud 0, then of cloud 1, ...), so one cloud's rows stay in the L2 ----
+    // ---- work of this workgroup: one channel slice and, of every cloud of its XCD in turn, a range of chunks (the workgroups
+    // of an XCD walk the XCD's clouds one after the other).  Measured alternative: all workgroups of an XCD on ONE slice at a
+    // time (2 MB of rows per XCD and phase instead of 4 MB, the filter slice re-staged per phase): 166-172 us instead of 154 at
+    // level 0 of the S3DIS plan, C = 128 — the staging is not bound by L2 misses (an explicit L2 warm-up of the next tile's rows
+    // did not help either: 165 us) but by the LDS-DMA path, ~12 B/clk per CU. ----
     const int WPX = (int)gridDim.x >> 3;
     const int xcd = (int)blockIdx.x & 7;
     const int wi = (int)blockIdx.x >> 3;
-    const int slice = wi % nslices;
-    const int nparts = WPX / nslices;
-    const int part = wi / nslices;
-    if (part >= nparts) return;
     const bool affine = (B & 7) == 0;
     const int nclouds = affine ? (B >> 3) : B;
-    const long long gpart = affine ? part : (long long)xcd * nparts + part;
-    const long long gparts = affine ? nparts : 8LL * nparts;
+    int sgroups = WPX < nslices ? WPX : nslices;                      // workgroup groups of the XCD, each on its own slices
+    const int nparts_x = WPX / sgroups;                               // workgroups of this XCD sharing a slice
+    const int sg = wi % sgroups, part_x = wi / sgroups;
+    if (part_x >= nparts_x) return;
+    const long long gpart = affine ? part_x : (long long)xcd * nparts_x + part_x;
+    const long long gparts = affine ? nparts_x : 8LL * nparts_x;
+    const int nsg = sgroups;
     const int ch_begin = (int)((long long)nchunks * gpart / gparts);
     const int span = (int)((long long)nchunks * (gpart + 1) / gparts) - ch_begin;
-    const int f_end = nclouds * span;
+    const int nsl = (nslices - sg + nsg - 1) / nsg;                    // slices of this group: sg, sg + nsg, ...
+    const int f_end = nclouds * nsl * span;
     if (f_end <= 0) return;
-    const int c0 = slice * 64;                       // first input channel of the slice
-    const bool second = input2 != nullptr && c0 >= Ca;
-    const int Cs = input2 == nullptr ? C : (second ? C - Ca : Ca);        // row stride of the source tensor
-    const float* src = (second ? input2 : input) + (c0 - (second ? Ca : 0)) + l16 * 4;
-
-    // ---- filter slice -> LDS planes (plane q: outputs 4q..4q+3 of every lane), zero rows ----
-    {
-        float* lf = reinterpret_cast<float*>(lds);
-        for (int e = tid; e < F * 16 * R; e += 64 * NW) {
-            const int f = e / (16 * R), rem = e - f * (16 * R);
-            const int l = rem / R, q = rem - l * R;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(filter + (size_t)f * CR + (size_t)(c0 + l * 4) * R + q * 4);
-            *reinterpret_cast<f32x4*>(lf + (size_t)q * PR * 64 + f * 64 + l * 4) = v;
-        }
-        for (int e = tid; e < 64 * R; e += 64 * NW) {
-            const int q = e >> 6, j = e & 63;
-            lf[(size_t)q * PR * 64 + F * 64 + j] = 0.f;
-        }
-        for (int e = tid; e < 64; e += 64 * NW) reinterpret_cast<float*>(lds + Map::RB)[(size_t)ucap * 64 + e] = 0.f;
-    }
 
     // ---- tile cursor: header of the current chunk in lanes (tile t -> lane t), the next chunk's prefetched ----
     int fH = 0;
-    auto chunk_of = [&](int f, int& b, int& chunk) {
-        const int ci = f / span, ch = ch_begin + (f - ci * span);
+    auto chunk_of = [&](int f, int& b, int& chunk, int& slice) {
+        const int si = f / (nclouds * span), rem = f - si * (nclouds * span);
+        const int ci = rem / span, ch = ch_begin + (rem - ci * span);
         b = affine ? xcd + 8 * ci : ci;
         chunk = b * nchunks + ch;
+        slice = sg + si * nsg;
     };
     auto load_hdr = [&](int f, int& hA, int& hO, int& hN) {
-        int b, chunk;
-        chunk_of(f, b, chunk);
+        int b, chunk, slice;
+        chunk_of(f, b, chunk, slice);
         const int* hp = chdr + (size_t)chunk * kLcHdrInts;
         hN = hp[0];
         hA = hp[1 + 2 * lane];
@@ -471,12 +521,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
     int tH = -1;
     auto next_tile = [&]() -> LcTile {
         LcTile t;
-        t.valid = 0; t.b = 0; t.chunk = 0; t.a = 0; t.uoff = 0;
+        t.valid = 0; t.b = 0; t.chunk = 0; t.slice = 0; t.a = 0; t.uoff = 0;
         for (;;) {
             if (tH + 1 < ntH) {
                 tH++;
                 t.valid = 1;
-                chunk_of(fH, t.b, t.chunk);
+                chunk_of(fH, t.b, t.chunk, t.slice);
                 t.a = __builtin_amdgcn_readlane(hA, tH);
                 t.uoff = __builtin_amdgcn_readlane(hO, tH);
                 return t;
@@ -500,52 +550,87 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
         if (t.valid && lane < RW && U > 0) v = rowlist[(size_t)t.chunk * kLcRowsPerChunk + t.uoff + r];
         return v;
     };
-    auto meta_of = [&](const LcTile& t) -> int {
+    // lanes of quarter q: {target id, count | pairs << 8} of target 4 * wave + q of the tile
+    auto meta_of = [&](const LcTile& t, int& m, int& cp) {
         const int tstart = t.a & 0xff, T = (t.a >> 8) & 0xff;
         const int rho = 4 * wave + (lane >> 4);
-        int v = 0;
-        if (t.valid && rho < T) v = tmeta[(size_t)t.chunk * kLcChunk + tstart + rho];
-        return v;
+        m = 0;
+        cp = 0;
+        if (t.valid && rho < T) {
+            const int2 v = *reinterpret_cast<const int2*>(tmeta + ((size_t)t.chunk * kLcChunk + tstart + rho) * 2);
+            m = v.x;
+            cp = v.y;
+        }
+    };
+    // the filter slice -> LDS planes (plane q: outputs 4q..4q+3 of every lane) and the zero rows
+    auto stage_filter = [&](int slice) {
+        const int c0 = slice * 64;
+        float* lf = reinterpret_cast<float*>(lds);
+        for (int e = tid; e < F * 16 * R; e += 64 * NW) {
+            const int f = e / (16 * R), rem = e - f * (16 * R);
+            const int l = rem / R, q = rem - l * R;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(filter + (size_t)f * CR + (size_t)(c0 + l * 4) * R + q * 4);
+            *reinterpret_cast<f32x4*>(lf + (size_t)q * PR * 64 + f * 64 + l * 4) = v;
+        }
+        for (int e = tid; e < 64 * R; e += 64 * NW) {
+            const int q = e >> 6, j = e & 63;
+            lf[(size_t)q * PR * 64 + F * 64 + j] = 0.f;
+        }
+        for (int e = tid; e < 64; e += 64 * NW) reinterpret_cast<float*>(lds + Map::RB)[(size_t)ucap * 64 + e] = 0.f;
+    };
+    // a tile's rows (LDS-DMA, four 256-B rows per wave instruction) and every wave's own four records
+    auto stage_tile = [&](const LcTile& t, int ids) {
+        const int tstart = t.a & 0xff, T = (t.a >> 8) & 0xff, U = t.a >> 16;
+        const int RW = ((U + 4 * NW - 1) / (4 * NW)) << 2;
+        const int c0 = t.slice * 64;
+        const bool second = input2 != nullptr && c0 >= Ca;
+        const int Cs = input2 == nullptr ? C : (second ? C - Ca : Ca);        // row stride of the source tensor
+        const float* inb = (second ? input2 : input) + (c0 - (second ? Ca : 0)) + l16 * 4 + (size_t)t.b * N * Cs;
+        for (int j = 0; j < RW; j += 4) {
+            const int i0 = wave * RW + j;
+            if (i0 >= U) break;
+            const int rid = __shfl(ids, j + (lane >> 4));
+            const float* gp = inb + (size_t)rid * Cs;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                             (__attribute__((address_space(3))) void*)(lds + Map::RB + (size_t)i0 * kLcRowBytes), 16, 0, 0);
+        }
+        if (wave * 4 < T) {
+            // four records of 384 B: one full DMA instruction and one of 32 lanes
+            const unsigned* gp = rec + ((size_t)t.chunk * kLcChunk + tstart + wave * 4) * kLcRecWords + lane * 4;
+            char* lp = lds + Map::RECB + wave * (4 * kLcRecWords * 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                             (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
+            if (lane < 32)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + 256),
+                                                 (__attribute__((address_space(3))) void*)(lp + 1024), 16, 0, 0);
+        }
     };
 
     LcTile t0 = next_tile();
     int ids0 = ids_of(t0);
-    int meta0 = meta_of(t0);
+    int m0, cp0;
+    meta_of(t0, m0, cp0);
     const unsigned lb = (unsigned)l16 << 4;
     const int rho = 4 * wave + (lane >> 4);
     const unsigned recaddr0 = (unsigned)(Map::RECB + rho * (kLcRecWords * 4));
-    __syncthreads();
+    int cur_slice = t0.slice;
+    stage_filter(cur_slice);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(dbg & 1)) stage_tile(t0, ids0);
 
     while (t0.valid) {
-        const int tstart = t0.a & 0xff, T = (t0.a >> 8) & 0xff, U = t0.a >> 16;
-        // ---- stage the tile: rows (LDS-DMA, four 256-B rows per wave instruction); every wave its own four records ----
-        if (!(dbg & 1)) {
-            const int RW = ((U + 4 * NW - 1) / (4 * NW)) << 2;
-            const float* inb = src + (size_t)t0.b * N * Cs;
-            for (int j = 0; j < RW; j += 4) {
-                const int i0 = wave * RW + j;
-                if (i0 >= U) break;
-                const int rid = __shfl(ids0, j + (lane >> 4));
-                const float* gp = inb + (size_t)rid * Cs;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                                 (__attribute__((address_space(3))) void*)(lds + Map::RB + (size_t)i0 * kLcRowBytes), 16, 0, 0);
-            }
-            if (wave * 4 < T) {
-                const unsigned* gp = rec + ((size_t)t0.chunk * kLcChunk + tstart + wave * 4) * kLcRecWords + lane * 4;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                                 (__attribute__((address_space(3))) void*)(lds + Map::RECB + wave * 1024), 16, 0, 0);
-            }
-        }
-        // ---- in flight under the DMA: the next tile's row ids and meta ----
+        const int T = (t0.a >> 8) & 0xff;
+        // ---- in flight under the DMA and the gather: the next tile's row ids and meta ----
         LcTile t1 = next_tile();
         const int ids1 = ids_of(t1);
-        const int meta1 = meta_of(t1);
+        int m1, cp1;
+        meta_of(t1, m1, cp1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        lc_barrier();
         // ---- gather: quarter-wave q of wave w takes target 4w + q of the tile (rank order: the four finish together) ----
         if (4 * wave < T && !(dbg & 2)) {
-            const int cnt = (int)((unsigned)meta0 >> 24);
-            int nmax = cnt;
+            const int cnt = cp0 & 0xff;
+            int nmax = cp0 >> 8;                         // pairs of this quarter's target
             nmax = max(nmax, __shfl_xor(nmax, 16));
             nmax = max(nmax, __shfl_xor(nmax, 32));
             nmax = uniform(nmax);
@@ -553,49 +638,57 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #pragma unroll
             for (int v = 0; v < 2 * R; v++) acc[v] = f32x2{0.f, 0.f};
             unsigned ra = recaddr0;
-            // eight edges per trip; the reads of four edges are issued before the first of their FMAs, the next four edges'
-            // reads before the FMAs of these (the compiler's own schedule waited for every edge's three reads); the entries
-            // of the next trip are requested a trip ahead
-            u32x4 e0 = lc_ld<u32x4>(ra), e1 = lc_ld<u32x4>(ra + 16);
-            for (int eb = 0; eb < nmax; eb += 8) {
+            // software pipeline over the pairs: two pairs (8 reads) in flight, the reads of pair p + 2 are issued right after
+            // the FMAs of pair p; the entries of the next four pairs are requested a trip ahead.  (Reads past the record's
+            // 48 entries fetch the next record or row bytes and form addresses nobody uses: pb + 4 >= nmax ends the loop.)
+            f32x4 xa[2], xb[2], w0[2], w1[2];
+            auto load_pair = [&](int i, unsigned e_slots, unsigned e_bin) {
+                const unsigned aa = lc_arow_a(e_slots, lb);
+                const unsigned ab = lc_arow_b(e_slots, lb);
+                const unsigned af = lc_afil(e_bin, lb);
+                xa[i] = lc_ld<f32x4>(aa + Map::RB);
+                xb[i] = lc_ld<f32x4>(ab + Map::RB);
+                w0[i] = lc_ld<f32x4>(af);
+                if constexpr (R == 2) w1[i] = lc_ld<f32x4>(af + PR * 256);
+            };
+            auto fma_pair = [&](int i) {
+                const f32x4 sx = xa[i] + xb[i];
+                const f32x2 x01 = {sx[0], sx[1]}, x23 = {sx[2], sx[3]};
+                if constexpr (R == 2) {
+                    lc_fma<0>(acc[0], x01, f32x2{w0[i][0], w0[i][1]});
+                    lc_fma<1>(acc[1], x01, f32x2{w0[i][2], w0[i][3]});
+                    lc_fma<0>(acc[2], x23, f32x2{w1[i][0], w1[i][1]});
+                    lc_fma<1>(acc[3], x23, f32x2{w1[i][2], w1[i][3]});
+                } else {
+                    acc[0] = __builtin_elementwise_fma(x01, f32x2{w0[i][0], w0[i][1]}, acc[0]);
+                    acc[1] = __builtin_elementwise_fma(x23, f32x2{w0[i][2], w0[i][3]}, acc[1]);
+                }
+            };
+            u32x4 ea = lc_ld<u32x4>(ra), eb = lc_ld<u32x4>(ra + 16);
+            load_pair(0, ea[0], ea[1]);
+            load_pair(1, ea[2], ea[3]);
+            for (int pb = 0; pb < nmax; pb += 4) {
                 ra += 32;
-                const unsigned ent[8] = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]};
-                f32x4 x[8], w0[8], w1[8];
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-#pragma unroll
-                    for (int uu = 0; uu < 4; uu++) {
-                        const int u = 4 * h + uu;
-                        const unsigned arow = lc_arow(ent[u], lb);
-                        const unsigned afil = lc_afil(ent[u], lb);
-                        x[u] = lc_ld<f32x4>(arow + Map::RB);
-                        w0[u] = lc_ld<f32x4>(afil);
-                        if constexpr (R == 2) w1[u] = lc_ld<f32x4>(afil + PR * 256);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // (entries past the record's 64 read the next record or the rows region: never used, eb + 8 >= nmax ends the loop)
-                e0 = lc_ld<u32x4>(ra);
-                e1 = lc_ld<u32x4>(ra + 16);
+                const u32x4 na = lc_ld<u32x4>(ra), nb = lc_ld<u32x4>(ra + 16);
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const f32x2 x01 = {x[u][0], x[u][1]}, x23 = {x[u][2], x[u][3]};
-                    if constexpr (R == 2) {
-                        lc_fma<0>(acc[0], x01, f32x2{w0[u][0], w0[u][1]});
-                        lc_fma<1>(acc[1], x01, f32x2{w0[u][2], w0[u][3]});
-                        lc_fma<0>(acc[2], x23, f32x2{w1[u][0], w1[u][1]});
-                        lc_fma<1>(acc[3], x23, f32x2{w1[u][2], w1[u][3]});
-                    } else {
-                        acc[0] = __builtin_elementwise_fma(x01, f32x2{w0[u][0], w0[u][1]}, acc[0]);
-                        acc[1] = __builtin_elementwise_fma(x23, f32x2{w0[u][2], w0[u][3]}, acc[1]);
-                    }
-                }
+                fma_pair(0);
+                load_pair(0, eb[0], eb[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                fma_pair(1);
+                load_pair(1, eb[2], eb[3]);
+                __builtin_amdgcn_sched_barrier(0);
+                fma_pair(0);
+                load_pair(0, na[0], na[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                fma_pair(1);
+                load_pair(1, na[2], na[3]);
+                __builtin_amdgcn_sched_barrier(0);
+                ea = na;
+                eb = nb;
             }
             if (rho < T) {
-                const int m = meta0 & 0xffffff;
                 const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.f;
-                float* op = output + ((size_t)t0.b * M + m) * CR + (size_t)(c0 + l16 * 4) * R;
+                float* op = output + ((size_t)t0.b * M + m0) * CR + (size_t)(t0.slice * 64 + l16 * 4) * R;
 #pragma unroll
                 for (int q = 0; q < R; q++) {
                     f32x4 o = {acc[2 * q][0] * inv, acc[2 * q][1] * inv, acc[2 * q + 1][0] * inv, acc[2 * q + 1][1] * inv};
@@ -603,10 +696,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 }
             }
         }
-        __syncthreads();
+        lc_barrier();
+        // ---- the next tile's rows and records (and filter slice, when the slice changes) ----
+        if (t1.valid) {
+            if (t1.slice != cur_slice) {
+                cur_slice = t1.slice;
+                stage_filter(cur_slice);
+            }
+            if (!(dbg & 1)) stage_tile(t1, ids1);
+        }
         t0 = t1;
-        ids0 = ids1;
-        meta0 = meta1;
+        m0 = m1;
+        cp0 = cp1;
     }
 }
 
@@ -642,10 +743,8 @@ static int launch_lc(int B, int N, int M, int F, int C, int ucap, const int* chd
     }
     const int nchunks = (M + kLcChunk - 1) / kLcChunk;
     const int nslices = C / 64;
-    // one (NW = 16) or two (NW = 8) workgroups per CU; the parts of a slice divide the chunks of every cloud of the XCD
-    int wpx = NW == 16 ? 32 : 64;
-    if (wpx < nslices) wpx = nslices;
-    wpx = (wpx / nslices) * nslices;
+    // one (NW = 16) or two (NW = 8) workgroups per CU
+    const int wpx = NW == 16 ? 32 : 64;
     hipLaunchKernelGGL(kern, dim3(8 * wpx), dim3(64 * NW), Map::TOTAL, st, B, N, M, F, C, nchunks, nslices, ucap, chdr, rec,
                        tmeta, rowlist, input, input2, Ca, filter, output, lc_dbg());
     return check_launch("sph3d_depthwise_conv3d_lds");
@@ -696,12 +795,13 @@ extern "C" int sph3d_spatial_order(int B, int N, const float* xyz, int* order, s
 
 extern "C" int sph3d_conv_plan_ucap(int F) { return lc_plan_ucap(F); }
 
+
 extern "C" int sph3d_conv_plan_sizes(int B, int M, size_t* hdr_ints, size_t* rec_words, size_t* meta_ints, size_t* rowlist_shorts)
 {
     const size_t nchunks = (size_t)((M + kLcChunk - 1) / kLcChunk);
     if (hdr_ints) *hdr_ints = (size_t)B * nchunks * kLcHdrInts;
-    if (rec_words) *rec_words = (size_t)B * nchunks * kLcChunk * kLcRecWords + 256;     // + read-ahead slack of the record DMA
-    if (meta_ints) *meta_ints = (size_t)B * nchunks * kLcChunk;
+    if (rec_words) *rec_words = (size_t)B * nchunks * kLcChunk * kLcRecWords + 512;     // + read-ahead slack of the record prefetch
+    if (meta_ints) *meta_ints = (size_t)B * nchunks * kLcChunk * 2;
     if (rowlist_shorts) *rowlist_shorts = (size_t)B * nchunks * kLcRowsPerChunk + 64;
     return SPH3D_OK;
 }

@@ -35,12 +35,14 @@ for n, rad, cs in levels:
         _plan.spatial_order(cur)
     t_plan = timeit(plan_only, 10)
     t_order = timeit(order_only, 10)
-    hdr = _plan.conv_plan(nidx, cnt, filt, 33, n)[0].cpu().numpy().reshape(B, -1, 132)
+    pl = _plan.conv_plan(nidx, cnt, filt, 33, n)
+    hdr = pl[0].cpu().numpy().reshape(B, -1, 132)
+    mt = pl[2].cpu().numpy().reshape(-1, 2)[:, 1]
     nt = int(hdr[:, :, 0].sum())
     a = hdr[:, :, 1::2]
     T = ((a >> 8) & 0xff)[a != 0]; U = (a >> 16)[a != 0]
-    print("N=%d: plan %.1f us, order %.1f us, tiles %d, targets/tile %.1f, rows/tile %.1f, avg cnt %.1f" %
-          (n, t_plan, t_order, nt, T.mean(), U.mean(), float(cnt.float().mean())))
+    print("N=%d: plan %.1f us, order %.1f us, tiles %d, targets/tile %.1f, rows/tile %.1f, avg cnt %.1f, avg pairs %.1f" %
+          (n, t_plan, t_order, nt, T.mean(), U.mean(), float(cnt.float().mean()), float((mt >> 8).sum()) / (B * n)))
     for C in cs:
         x = torch.randn(B, n, C, device=dev); w = torch.randn(33, C, 2, device=dev)
         _plan.set_mode("lds")
