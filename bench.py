@@ -343,6 +343,12 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--atan2", choices=("ocml", "shared"), default="ocml",
+                    help="angle function of the spherical-kernel binning: 'ocml' = ROCm's device-library atan2f, the function the "
+                         "reference's own kernel calls when built for this GPU (bins bit-identical to the reference build); "
+                         "'shared' = the correctly rounded atan2f shared with the CPU oracle")
+    ap.add_argument("--conv", choices=("gather", "lds"), default="gather",
+                    help="depthwise forward kernel: 'gather' (conv3d.hip) or 'lds' (convlds.hip: LDS tiles + per-graph plan)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -356,6 +362,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     pinned_cpus = hdist.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     _lib.lib()
+    from sph3d_gcn_amd import tf_buildkernel, _plan
+    tf_buildkernel.set_atan2(args.atan2)          # reaches the fused graph kernel too (tf_nnquery.build_sphere_graph)
+    _plan.set_mode(args.conv)
 
     batches = [make_batch(rank, dev, w) for w in range(NUM_BATCHES)]
     torch.cuda.synchronize()
@@ -526,6 +535,11 @@ def main():
                                       "overlapped with backward)" % (world, len(flat.buckets)),
                        "resident_batches": NUM_BATCHES, "event_pass_steps": ev_steps,
                        "params": nparams, "launch_mode": mode,
+                       "atan2": args.atan2,
+                       "bin_ids": ("bit-identical to the reference build (same ocml atan2f; tests/test_gpu_round3.py)" if args.atan2 == "ocml"
+                                   else "shared correctly-rounded atan2f: == CPU oracle, differs from the reference build within an "
+                                        "ulp of a bin boundary (0.07 % of level-0 slots)"),
+                       "conv_forward": args.conv,
                        "world_size": dist.get_world_size() if dist.is_initialized() else 1,
                        "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "rccl_version": _rccl_version(), "cpus_per_rank": pinned_cpus},

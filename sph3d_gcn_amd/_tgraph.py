@@ -24,6 +24,7 @@ def _ident(t):
 def clear():
     _cache.clear()
     _orders.clear()
+    _unique.clear()
 
 
 # processing order of the source points of a graph (a permutation per cloud, spatially sorted): optional hint for
@@ -50,19 +51,29 @@ def source_order(nn_index):
     return order
 
 
-def peek(nn_index, nn_count, n_src):
-    """the cached transpose of an un-binned, un-weighted graph, or None (never builds: for gradients that have a fallback)"""
+_unique = set()        # keys of cached transposes whose builder promised rows without repeated neighbour ids
+
+
+def peek(nn_index, nn_count, n_src, need_unique_rows=False):
+    """the cached transpose of an un-binned, un-weighted graph, or None (never builds: for gradients that have a fallback).
+    need_unique_rows: only a transpose whose builder promised that no row of nn_index lists a point twice (the max-pool
+    gradient as a gather would add such a point's gradient once per repeat; the reference adds it once: ADVICE r3)"""
     key = (_ident(nn_index), _ident(nn_count), _ident(None), _ident(None), int(n_src), 1, tuple(nn_index.shape))
-    return transpose(nn_index, nn_count, n_src) if key in _cache else None
+    if key not in _cache or (need_unique_rows and key not in _unique):
+        return None
+    return transpose(nn_index, nn_count, n_src)
 
 
-def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1, counted_workspace=None):
+def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1, counted_workspace=None, unique_rows=False):
     """-> (offsets[B*(n_src*F+1)] i32, ent_key[B*M*K] i32, ent_scale[B*M*K] f32, active_bins[F+1] i32 | None) on
     nn_index's device; F = num_bins (the filter's bin count when bin_index is given, else 1); active_bins (count, then
     the bins that occur) is produced for binned graphs only.  counted_workspace: a transpose workspace whose counting
-    phase has already run (tf_nnquery.build_sphere_graph did it inside the neighbour search): only scan + fill remain"""
+    phase has already run (tf_nnquery.build_sphere_graph did it inside the neighbour search): only scan + fill remain.
+    unique_rows: the caller's promise that no row lists a point twice (rows of the ball query and rows gathered from them)"""
     F = int(num_bins) if bin_index is not None else 1
     key = (_ident(nn_index), _ident(nn_count), _ident(bin_index), _ident(weight), int(n_src), F, tuple(nn_index.shape))
+    if unique_rows:
+        _unique.add(key)
     cur_raw = _lib.current_raw_stream()
     hit = _cache.get(key)
     if hit is not None:
@@ -106,5 +117,5 @@ def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1
     ev.record(cur)
     _cache[key] = (out, (nn_index, nn_count, bin_index, weight), ev, {cur_raw})
     while len(_cache) > _MAX_ENTRIES:
-        _cache.popitem(last=False)
+        _unique.discard(_cache.popitem(last=False)[0])
     return out

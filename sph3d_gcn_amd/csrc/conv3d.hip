@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64 * kMultiWaves) void dwconv_fwd_multi(
             int binv = binIndex[row * K + mykc];
             binv = binv < 0 ? 0 : (binv >= F ? F - 1 : binv);     // out-of-range bin ids: same clamp as the transposed graph
             binv = myk < cnt ? binv : F;
-            const unsigned pk = (unsigned)idxv | ((unsigned)binv << 24);      // N <= 2^24, F <= 254: launcher
+            const unsigned pk = ((unsigned)idxv & 0xffffffu) | ((unsigned)binv << 24);      // N <= 2^24, F <= 254: launcher; an id outside [0, 2^24) must not reach the bin field
             static_assert(64 % (SB * EPL) == 0, "batches must tile the 64-edge chunk (no index clamps)");
             // ... then consumed SB wave loads (SB*EPL edges) at a time: all their gathers are in flight before the
             // first FMA (the kernel is latency-bound otherwise)

@@ -18,6 +18,7 @@
 // Clouds larger than 1024 * 24 points fall back to a kernel that keeps the running distance in a
 // caller-provided workspace (the reference's `temp`) and re-reads xyz from L2.
 // -ffp-contract=off: d = (dx*dx + dy*dy) + dz*dz must round like the oracle.
+#include <cstdlib>
 #include "common.hpp"
 
 namespace sph3d {
@@ -136,10 +137,13 @@ __global__ __launch_bounds__(1024) void fps_reg_kernel(int b, int n, int m,
 
 // Fallback for very large clouds: running distance in global workspace (the reference's temp[32][n]),
 // xyz re-read from L2 each round.  Same arithmetic and tie-break.
+// `gate` != nullptr: run only if *gate != 0 (the co-operative kernel's error word: its repair pass, see the launcher).
 __global__ __launch_bounds__(1024) void fps_big_kernel(int b, int n, int m, const float* __restrict__ dataset,
-                                                       float* __restrict__ temp, int* __restrict__ idxs)
+                                                       float* __restrict__ temp, int* __restrict__ idxs,
+                                                       const int* __restrict__ gate = nullptr)
 {
     __shared__ FpsSlot slots[2][16];
+    if (gate != nullptr && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     const int t = (int)threadIdx.x;
     const int wave = uniform(t >> 6);
     const int nwaves = (int)(blockDim.x >> 6);
@@ -210,7 +214,10 @@ __global__ __launch_bounds__(1024) void fps_big_kernel(int b, int n, int m, cons
 // reads).  The maximum of the upper 50 bits is the reference's winner: larger distance, then lower thread id t = k mod 1024,
 // then lower k (tf_sample_gpu.cu:49,56-66: strict > inside a thread, left entry wins in the tree).  The winner's coordinates
 // are read from the (read-only) cloud.  Every spin is bounded: a workgroup that waits 2^22 polls sets the error word and the
-// kernel ends (the launcher's workgroups are all resident by construction: B * G <= 128 workgroups of 1024 threads).
+// kernel ends.  The launch is an ordinary one: its B * G <= 128 workgroups of 1024 threads are co-resident on an idle GPU, but
+// nothing guarantees that beside other streams' kernels or another process — so a time-out must not cost
+// correctness: the launcher queues fps_big_kernel behind it, gated on the error word, which recomputes every cloud's samples
+// the slow way when (and only when) the co-operative pass gave up.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kCoopP = 4;                  // points per thread
 constexpr int kCoopPts = kRefBlock * kCoopP;
@@ -335,14 +342,28 @@ static int coop_groups(int b, int n)
     return (G <= 64 && (long long)b * G <= 128) ? G : 0;
 }
 
+static size_t coop_slot_bytes(int b, int G) { return (256 + sizeof(unsigned long long) * (size_t)b * 2 * G + 255) & ~(size_t)255; }
+
+// test hook: SPH3D_FPS_FORCE_TIMEOUT=1 starts the co-operative kernel with its error word already set, so the repair pass runs
+static int fps_force_timeout()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("SPH3D_FPS_FORCE_TIMEOUT");
+        v = (e && atoi(e) != 0) ? 1 : 0;
+    }
+    return v;
+}
+
 extern "C" size_t sph3d_farthest_point_sample_workspace(int b, int n, int m)
 {
     (void)m;
     if (n <= kRefBlock * kFpsMaxRegPoints) return 0;
     const int G = coop_groups(b, n);
-    if (G) return 256 + sizeof(unsigned long long) * (size_t)b * 2 * G;          // error word + granule slots
     const int g = b < kFpsBigGrid ? b : kFpsBigGrid;
-    return sizeof(float) * (size_t)g * n;
+    const size_t big = sizeof(float) * (size_t)g * n;                            // fps_big_kernel's running distances
+    if (G) return coop_slot_bytes(b, G) + big;                                   // error word + granule slots, then the repair pass's
+    return big;
 }
 
 extern "C" int sph3d_farthest_point_sample(int b, int n, int m, const float* inp, int* out,
@@ -372,14 +393,25 @@ extern "C" int sph3d_farthest_point_sample(int b, int n, int m, const float* inp
         }
         const int G = coop_groups(b, n);
         if (G) {
-            int rc = check_hip(hipMemsetAsync(workspace, 0, need, st), "FarthestPointSample: memset");
+            const size_t head = coop_slot_bytes(b, G);
+            int rc = check_hip(hipMemsetAsync(workspace, 0, head, st), "FarthestPointSample: memset");
             if (rc) return rc;
             int* err = (int*)workspace;
+            if (fps_force_timeout()) {
+                rc = check_hip(hipMemsetAsync(err, 1, 1, st), "FarthestPointSample: memset");
+                if (rc) return rc;
+            }
             unsigned long long* slots = (unsigned long long*)((char*)workspace + 256);
             hipLaunchKernelGGL(fps_coop_kernel, dim3(b * G), dim3(kRefBlock), 0, st, n, m, G, inp, slots, err, out);
+            rc = check_launch("sph3d_farthest_point_sample (co-operative pass)");
+            if (rc) return rc;
+            // repair pass: returns at once unless the co-operative pass timed out (then every cloud is resampled, bit-exactly)
+            const int g = b < kFpsBigGrid ? b : kFpsBigGrid;
+            hipLaunchKernelGGL(fps_big_kernel, dim3(g), dim3(kRefBlock), 0, st, b, n, m, inp, (float*)((char*)workspace + head), out,
+                               (const int*)err);
         } else {
             const int g = b < kFpsBigGrid ? b : kFpsBigGrid;
-            hipLaunchKernelGGL(fps_big_kernel, dim3(g), dim3(kRefBlock), 0, st, b, n, m, inp, (float*)workspace, out);
+            hipLaunchKernelGGL(fps_big_kernel, dim3(g), dim3(kRefBlock), 0, st, b, n, m, inp, (float*)workspace, out, (const int*)nullptr);
         }
     }
 #undef SPH3D_FPS

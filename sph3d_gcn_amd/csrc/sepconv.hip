@@ -119,7 +119,7 @@ __global__ __launch_bounds__(1024) void sepconv_fused_kernel(
                     int binv = binIndex[row * K + mykc];
                     binv = binv < 0 ? 0 : (binv >= F ? F - 1 : binv);
                     binv = myk < cnt ? binv : F;
-                    const unsigned pk = (unsigned)idxv | ((unsigned)binv << 24);
+                    const unsigned pk = ((unsigned)idxv & 0xffffffu) | ((unsigned)binv << 24);
                     for (int k0 = 0; k0 < kn; k0 += 4 * EPL) {
                         float4 x[4];
                         unsigned fo[4];

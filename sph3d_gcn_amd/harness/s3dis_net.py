@@ -102,6 +102,7 @@ class GraphPlan:
         self._enc_ev, self._dec_ev, self._pool_ev = {}, {}, {}
         self._synced = set()
         self.net_input = None
+        self._in_key = None
         if self.use_side:
             self.main = torch.cuda.current_stream()
             streams = _side_stream.get(xyz.device)
@@ -135,6 +136,7 @@ class GraphPlan:
                 # the network's input features (centred coordinates + colours, models/SPH3D_s3dis.py:11-19,38-41) depend on the
                 # batch only: prepared here, ahead of the feature path (one reduction + four small kernels, 60 us of main-stream time)
                 self.net_input = _net_input(points, config)
+                self._in_key = (points.data_ptr(), points._version, tuple(points.shape))
                 self._in_ev = torch.cuda.Event()
                 self._in_ev.record(s_fps)
                 self._sampling_chain(s_fps)
@@ -191,7 +193,8 @@ class GraphPlan:
             # the max-pool gradient gathers over the transposed pooling graph when one exists (tf_pool3d): built here, off the
             # critical path, like the transposes of the convolution graphs
             from .. import _tgraph
-            _tgraph.transpose(g["inter_idx"], g["inter_cnt"], self.xyz_layers[l].shape[1])
+            # (rows gathered from the ball query's rows: ascending, distinct neighbour ids)
+            _tgraph.transpose(g["inter_idx"], g["inter_cnt"], self.xyz_layers[l].shape[1], unique_rows=True)
 
     def _make_dec(self, l):
         c = self.config
@@ -265,7 +268,10 @@ class GraphPlan:
 
     def input(self, points):
         """centred coordinates + colours of the batch (prepared on the sampling stream when the plan runs on side streams)"""
-        if self.use_side and self.net_input is not None:
+        # the cached tensor belongs to the batch the plan was built from: a plan reused with other features on the same
+        # coordinates (same xyz, new colours) gets them recomputed (ADVICE r3)
+        if (self.use_side and self.net_input is not None
+                and self._in_key == (points.data_ptr(), points._version, tuple(points.shape))):
             self._sync(("input",), self._in_ev, [self.net_input])
             return self.net_input
         return _net_input(points, self.config)

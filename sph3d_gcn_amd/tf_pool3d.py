@@ -151,11 +151,12 @@ class _MaxPool3dFn(torch.autograd.Function):      # eager fast path (see tf_conv
     @staticmethod
     def backward(ctx, grad_output, grad_index):
         input, max_index, nn_index, nn_count = ctx.saved_tensors
-        # a transposed pooling graph someone built ahead of time (the harness does, on its graph stream): gather, no atomics;
-        # otherwise the reference's scatter (building the transpose here would cost more than it saves)
+        # a transposed pooling graph someone built ahead of time WITH the promise that no row repeats a point (the harness
+        # does, on its graph stream: rows of the ball query): gather, no atomics; otherwise the reference's scatter, which adds
+        # a point's gradient once however often a row lists it (tf_pool3d_gpu.cu:38-50)
         tg = None
         if input.is_cuda and nn_index.dtype == torch.int32 and nn_count.dtype == torch.int32:
-            tg = _tgraph.peek(nn_index, nn_count, input.shape[1])
+            tg = _tgraph.peek(nn_index, nn_count, input.shape[1], need_unique_rows=True)
         if tg is not None:
             return _max_pool3d_grad_t_impl(input, grad_output, max_index, nn_count, tg), None, None
         return _max_pool3d_grad_impl(input, grad_output, max_index), None, None
@@ -194,7 +195,7 @@ class _MaxPool3dSkipFn(torch.autograd.Function):
         input, max_index, nn_index, nn_count = ctx.saved_tensors
         tg = None
         if input.is_cuda and nn_index.dtype == torch.int32 and nn_count.dtype == torch.int32:
-            tg = _tgraph.peek(nn_index, nn_count, input.shape[1])
+            tg = _tgraph.peek(nn_index, nn_count, input.shape[1], need_unique_rows=True)
         if grad_output is None:
             return grad_skip, None, None
         if tg is not None:

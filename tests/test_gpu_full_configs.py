@@ -12,7 +12,9 @@ import pytest
 import torch
 
 import oracle
+from _errors import assert_per_element
 from sph3d_gcn_amd import tf_nnquery, tf_buildkernel, tf_conv3d, tf_pool3d, tf_unpool3d, tf_sample
+from sph3d_gcn_amd import sph3gcn_util as s3g_util
 from sph3d_gcn_amd.harness import modelnet_net, shapenet_net, s3dis_net, synth
 
 pytestmark = pytest.mark.gpu
@@ -41,6 +43,29 @@ def _graph_properties(idx, cnt, K, N):
     return idx_n, cnt_n
 
 
+def _conv_vs_oracle(dev, xyz_db, xyz_q, idx, cnt, filt, F, C, r, what, seed=0):
+    """depthwise forward and both gradients of ONE cloud's graph (numpy: xyz [1, N, 3], idx / cnt / filt of that cloud) at
+    the plan's channel count, against the oracle: the 1e-5 bar on the activations and the per-element bound of
+    tests/_errors.py on activations and gradients"""
+    rng = np.random.RandomState(seed + C * 3 + r)
+    N, M = xyz_db.shape[1], idx.shape[1]
+    x = rng.randn(1, N, C).astype(np.float32)
+    w = rng.randn(F, C, r).astype(np.float32)
+    go = rng.randn(1, M, C * r).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    xt, wt = t(x).requires_grad_(True), t(w).requires_grad_(True)
+    out = tf_conv3d.depthwise_conv3d(xt, wt, t(idx), t(cnt), t(filt))
+    out.backward(t(go))
+    out_o = oracle.depthwise_conv3d(x, w, idx, cnt, filt)
+    gi_o, gf_o = oracle.depthwise_conv3d_grad(x, w, go, idx, cnt, filt)
+    np.testing.assert_allclose(_n(out), out_o, **TOL)
+    ax, aw, ago = np.abs(x), np.abs(w), np.abs(go)
+    mi, mf = oracle.depthwise_conv3d_grad(ax, aw, ago, idx, cnt, filt)
+    assert_per_element(_n(out), out_o, oracle.depthwise_conv3d(ax, aw, idx, cnt, filt), what + " forward")
+    assert_per_element(_n(xt.grad), gi_o, mi, what + " grad_input")
+    assert_per_element(_n(wt.grad), gf_o, mf, what + " grad_filter")
+
+
 def test_modelnet_full_config(dev):
     B, N = 32, 10000
     cfg = modelnet_net.modelnet_config(N)
@@ -63,6 +88,26 @@ def test_modelnet_full_config(dev):
     np.testing.assert_array_equal(_n(filt), oracle.spherical_kernel(xyz[sl], xyz[sl], io, co, do, cfg.radius[0], cfg.kernel))
     fps = tf_sample.farthest_point_sample(200, pts[sl])
     np.testing.assert_array_equal(_n(fps), oracle.farthest_point_sample(200, xyz[sl]))
+    # the plan's odd channel counts on ONE cloud of the full-size plan, forward + both gradients against the oracle
+    # (models/SPH3D_modelnet.py:47-93): level 0 = 32 mlp + 3 raw channels, r = 2 (10 000 points, K = 64, 33 bins);
+    # level 1 = 64 + 3, r = 1 (2500 points); level 2 = 128 + 3, r = 1 (625 points); the global convolution = one query
+    # (the centroid) over the 156 remaining points, kernel [8, 2, 1] -> 17 bins, 131 channels, r = 2
+    one = slice(3, 4)
+    cur = modelnet_net.normalize_xyz(pts[one]).contiguous()
+    levels = [(35, 2), (67, 1), (131, 1)]
+    for l, (C, r) in enumerate(levels):
+        cn = _n(cur)
+        i_l, c_l, d_l = tf_nnquery.build_sphere_neighbor(cur, cur, cfg.radius[l], None, cfg.nn_uplimit[l])
+        f_l = tf_buildkernel.spherical_kernel(cur, cur, i_l, c_l, d_l, cfg.radius[l], cfg.kernel)
+        _conv_vs_oracle(dev, cn, cn, _n(i_l), _n(c_l), _n(f_l), 33, C, r, "modelnet level %d C=%d r=%d" % (l, C, r))
+        pick = tf_sample.farthest_point_sample(cfg.num_sample[l], cur)
+        cur = torch.gather(cur, 1, pick.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    assert cur.shape[1] == 156
+    query = cur.mean(dim=1, keepdim=True)
+    gi, gc, gd = s3g_util.build_global_graph(cur, query, 100.0)
+    gf = tf_buildkernel.spherical_kernel(cur, query, gi, gc, gd, 100.0, [8, 2, 1])
+    assert gi.shape == (1, 1, 156) and int(gc.min()) == 156
+    _conv_vs_oracle(dev, _n(cur), _n(query), _n(gi), _n(gc), _n(gf), 17, 131, 2, "modelnet global conv K=156 F=17 C=131 r=2")
 
 
 def test_shapenet_full_config(dev):
@@ -84,6 +129,13 @@ def test_shapenet_full_config(dev):
     np.testing.assert_array_equal(_n(cnt), co)
     fps = tf_sample.farthest_point_sample(cfg.num_sample[0], pts[sl])
     np.testing.assert_array_equal(_n(fps), oracle.farthest_point_sample(cfg.num_sample[0], xyz[sl]))
+    # one cloud of the full-size plan: level-0 depthwise activation and both gradients at the plan's channel counts
+    # (64 -> 128 and 128 -> 128 layers: C = 64 and 128, r = 2; models/SPH3D_shapenet.py:56-66) against the oracle
+    one = slice(10, 11)
+    i0, c0, d0 = tf_nnquery.build_sphere_neighbor(pts[one], pts[one], cfg.radius[0], None, cfg.nn_uplimit[0])
+    f0 = tf_buildkernel.spherical_kernel(pts[one], pts[one], i0, c0, d0, cfg.radius[0], cfg.kernel)
+    for C in (64, 128):
+        _conv_vs_oracle(dev, xyz[one], xyz[one], _n(i0), _n(c0), _n(f0), 33, C, 2, "shapenet level 0 C=%d r=2" % C)
 
 
 def test_s3dis_bench_config_full_step(dev):

@@ -15,6 +15,7 @@ import pytest
 import torch
 
 import oracle
+from _errors import assert_per_element
 from oracle import ref_gpu
 from sph3d_gcn_amd import tf_nnquery, tf_buildkernel, tf_conv3d, tf_sample, _tgraph
 from sph3d_gcn_amd import sph3gcn_util as s3g_util
@@ -110,6 +111,11 @@ def test_conv_gradient_at_the_bench_shape_vs_oracle(dev, C):
     sf = max(1.0, float(np.abs(gf_o).max()))
     np.testing.assert_allclose(gi_n[b0] / si, gi_o[0] / si, **TOL)
     np.testing.assert_allclose(gf_n / sf, gf_o / sf, **TOL)
+    # per element, against the sum of the magnitudes of each element's terms (tests/_errors.py)
+    mi, mf = oracle.depthwise_conv3d_grad(np.abs(x[b0:b0 + 1]), np.abs(w), np.abs(go[b0:b0 + 1]), idx_n[b0:b0 + 1],
+                                          cnt_n[b0:b0 + 1], filt_n[b0:b0 + 1])
+    assert_per_element(gi_n[b0], gi_o[0], mi[0], "bench-shape conv grad_input C=%d" % C)
+    assert_per_element(gf_n, gf_o, mf, "bench-shape conv grad_filter C=%d" % C)
     other = np.delete(np.arange(B), b0)
     assert (gi_n[other] == 0).all()                 # clouds with a zero upstream gradient: exact zeros
     # the forward at the same shape, same slice
@@ -362,6 +368,30 @@ def test_fps_large_clouds_cooperative_kernel_bitexact(dev, B, n, m):
     print("\nFPS %d x %d -> %d: %.1f ms" % (B, n, m, dt * 1e3))
 
 
+def test_fps_cooperative_time_out_is_repaired(dev):
+    """the co-operative kernel's workgroups are co-resident only by construction of the launch; if one of
+    its bounded spins ever times out (other streams' kernels or another process on the GPU) the error word is set and the
+    repair pass queued behind it — fps_big_kernel gated on that word — resamples every cloud.  SPH3D_FPS_FORCE_TIMEOUT=1
+    starts the kernel with the word already set: the result must still be the oracle's sequence."""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r)
+        import oracle
+        from sph3d_gcn_amd import tf_sample
+        rng = np.random.RandomState(3)
+        xyz = (rng.rand(2, 30000, 3) * np.array([6.0, 6.0, 3.0])).astype(np.float32)
+        xyz[:, 5000:5100] = xyz[:, 100:200]
+        got = tf_sample.farthest_point_sample(400, torch.from_numpy(xyz).cuda()).cpu().numpy()
+        assert np.array_equal(got, oracle.farthest_point_sample(400, xyz)), "repair pass != oracle"
+        print("REPAIRED_OK")
+    """ % root)
+    env = dict(os.environ, SPH3D_FPS_FORCE_TIMEOUT="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "REPAIRED_OK" in r.stdout, r.stdout + r.stderr
+
+
 # ---- fused separable convolution for inference (csrc/sepconv.hip; SURVEY 8f.3) -----------------------------------------
 # (kind, B, N, M, radius, K, kernel, C, r, Cout)
 SEPCONV_CASES = [
@@ -491,7 +521,7 @@ def test_max_pool_gradient_gather_form_equals_scatter_form_and_oracle(dev, case)
     def run(with_transpose):
         _tgraph.clear()
         if with_transpose:
-            _tgraph.transpose(idx, cnt, N)
+            _tgraph.transpose(idx, cnt, N, unique_rows=True)        # rows of the ball query: no repeated neighbour ids
         xin = _t(x, dev).requires_grad_(True)
         out, mi = tf_pool3d.max_pool3d(xin, idx, cnt)
         _lib.timing_start()
@@ -509,6 +539,38 @@ def test_max_pool_gradient_gather_form_equals_scatter_form_and_oracle(dev, case)
     g_o = oracle.max_pool3d_grad(x, go, mi_s)
     np.testing.assert_allclose(g_t, g_o, **TOL)
     assert np.abs(g_t[:, 0]).sum() > 0              # the empty rows' gradients did reach point 0
+
+
+def test_max_pool_gradient_with_repeated_neighbour_ids_uses_the_scatter(dev):
+    """max_pool3d takes arbitrary nn_index.  A row that lists a point twice must add that point's gradient ONCE
+    (tf_pool3d_gpu.cu:38-50); the gather over the transposed graph would add it per repeat, so it is used only for
+    transposes built with the unique_rows promise — a cached transpose without it (here: built by the avg-pool gradient
+    of the same graph) leaves the max-pool gradient on the scatter path.  Checked against the oracle."""
+    from sph3d_gcn_amd import tf_pool3d, _lib
+    B, N, M, C, K = 2, 120, 40, 8, 6
+    rng = np.random.RandomState(1)
+    idx = rng.randint(0, N, size=(B, M, K)).astype(np.int32)
+    idx[:, :, 3] = idx[:, :, 1]                      # every row repeats a neighbour
+    idx[:, ::2, 5] = idx[:, ::2, 1]                  # ... half of them twice
+    cnt = np.full((B, M), K, np.int32)
+    x = rng.randn(B, N, C).astype(np.float32)
+    go = rng.randn(B, M, C).astype(np.float32)
+    it, ct = _t(idx, dev), _t(cnt, dev)
+    _tgraph.clear()
+    xa = _t(x, dev).requires_grad_(True)
+    tf_pool3d.avg_pool3d(xa, it, ct).sum().backward()            # caches a transpose of this graph, no promise
+    assert _tgraph.peek(it, ct, N) is not None and _tgraph.peek(it, ct, N, need_unique_rows=True) is None
+    xin = _t(x, dev).requires_grad_(True)
+    out, mi = tf_pool3d.max_pool3d(xin, it, ct)
+    _lib.timing_start()
+    try:
+        out.backward(_t(go, dev))
+    finally:
+        names = [c[0] for c in _lib.timing_stop()]
+    assert "sph3d_max_pool3d_grad" in names and "sph3d_max_pool3d_grad_t" not in names
+    out_o, mi_o = oracle.max_pool3d(x, idx, cnt)
+    np.testing.assert_array_equal(_n(mi), mi_o)
+    np.testing.assert_allclose(_n(xin.grad), oracle.max_pool3d_grad(x, go, mi_o), **TOL)
 
 
 # ---- seeded random shapes: the new neighbour-search scan and the fused inference layer against the oracle ------------------
@@ -712,7 +774,7 @@ def test_max_pool_with_skip_sums_both_gradients_in_the_pooling_kernel(dev):
     for mode in ("fused", "fused_no_transpose", "separate"):
         _tgraph.clear()
         if mode != "fused_no_transpose":
-            _tgraph.transpose(idx, cnt, N)
+            _tgraph.transpose(idx, cnt, N, unique_rows=True)
         xin = _t(x, dev).requires_grad_(True)
         if mode == "separate":
             pooled, _ = tf_pool3d.max_pool3d(xin, idx, cnt)
