@@ -411,11 +411,16 @@ def main():
     # step would lengthen the very interval being measured.
     ev_steps = min(args.steps, 20)
     _lib.timing_start()
+    flat.time_wait_events = True            # + an event pair around the wait for the gradient all-reduce (main stream)
     for _ in range(ev_steps):
         one_step()
     torch.cuda.synchronize()
     events = _lib.timing_stop()
+    flat.time_wait_events = False
+    ar_wait_ms = [a.elapsed_time(b) for a, b in flat.wait_events]
 
+    # every rank's own time for the K timed steps (diagnosis of a slow rank), then the contract's MAX over ranks
+    per_rank_s = hdist.gather_floats(elapsed, world, dev)
     elapsed = reduce_max_seconds(elapsed, world, dev)
 
     # ---- per-kernel device time from the HIP events recorded during the timed steps ----
@@ -543,6 +548,18 @@ def main():
                        "world_size": dist.get_world_size() if dist.is_initialized() else 1,
                        "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "rccl_version": _rccl_version(), "cpus_per_rank": pinned_cpus},
+            # multi-GPU diagnosis: each rank's ms/step over the same K steps, the gradient buckets, where
+            # their all-reduces were started, and how long the main stream waited for them before the optimiser step
+            "dist": {"per_rank_ms_per_step": [round(x / args.steps * 1e3, 3) for x in per_rank_s],
+                     "rank_ms_per_step_min_max": [round(min(per_rank_s) / args.steps * 1e3, 3),
+                                                  round(max(per_rank_s) / args.steps * 1e3, 3)],
+                     "bucket_bytes": [4 * (f1 - f0) for (_i0, _i1, f0, f1) in flat.buckets],
+                     "buckets_started_in_backward": flat.stats["buckets_started_in_backward"],
+                     "buckets_started_after_backward": flat.stats["buckets_started_after_backward"],
+                     "allreduce_wait_stream_ms_per_step": (round(sum(ar_wait_ms) / max(1, len(ar_wait_ms)), 4) if ar_wait_ms else 0.0),
+                     "allreduce_wait_host_ms_per_step": round(flat.stats["allreduce_wait_host_s"] / max(1, flat.stats["allreduce_calls"]) * 1e3, 4),
+                     "note": "rank 0's counters; allreduce_wait_stream = HIP events around the wait in FlatGradAllReduce.all_reduce() "
+                             "on the main stream during the %d event-pass steps (0 at one GPU: no collective is issued)" % ev_steps},
             "loss": round(float(loss), 5),
             "sph3d_calls_ms_per_step_summed_over_streams": round(sph3d_ms, 3),
             "families_ms_per_step": families,

@@ -80,6 +80,16 @@ def pin_rank(local_rank, local_world, want_numa=True):
         return 0
 
 
+def gather_floats(value, world, dev):
+    """every rank's `value` (a float) on every rank, in rank order"""
+    if world <= 1 or not dist.is_initialized():
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
+
+
 def shard_range(total, rank, world):
     """Contiguous [begin, end) of `total` clouds owned by `rank` (remainder spread over the first ranks)."""
     base, rem = divmod(total, world)
@@ -101,7 +111,14 @@ class FlatGradAllReduce:
     xGMI rings are per-link bound, so a bucket is several MiB (default 4 MiB: 4 buckets for the 15-MiB S3DIS net); with
     one replica no collective is issued and the hooks only do the concatenations."""
 
-    def __init__(self, params, bucket_bytes=4 << 20):
+    def __init__(self, params, bucket_bytes=4 << 20, collective=None):
+        """collective: optional replacement of dist.all_reduce for tests — called as collective(view) right after the
+        bucket's concatenation, on the stream the concatenation was issued on; returns an object with .wait() (or None)"""
+        self._collective = collective
+        self.stats = {"allreduce_wait_host_s": 0.0, "allreduce_calls": 0, "buckets_started_in_backward": 0,
+                      "buckets_started_after_backward": 0}
+        self.time_wait_events = False          # record a HIP-event pair around the wait in all_reduce() (bench.py's event pass)
+        self.wait_events = []
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
@@ -136,9 +153,19 @@ class FlatGradAllReduce:
         i0, i1, f0, f1 = self.buckets[bi]
         parts = [(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(grads, self.params[i0:i1])]
         view = self.flat[f0:f1]
+        # ORDER: the concatenation is issued on the CURRENT stream — inside a tensor hook that is the stream of the backward
+        # node that produced the bucket's last gradient — and the collective is started right behind it from the same
+        # thread: ProcessGroupNCCL (= RCCL) orders its communication stream after an event it records on the current stream
+        # at this call, so the all-reduce cannot read the bucket before the concatenation has written it, whichever stream
+        # the backward pass runs on (tests/test_gpu_dist.py checks exactly this with a stand-in collective).
         torch.cat(parts, out=view)
-        if self._world() > 1:
+        if self._collective is not None:
+            w = self._collective(view)
+            if w is not None:
+                self._pending.append(w)
+        elif self._world() > 1:
             self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+        self.stats["buckets_started_in_backward" if self._armed else "buckets_started_after_backward"] += 1
         self._done.add(bi)
 
     def _make_hook(self, bi, i):
@@ -180,10 +207,22 @@ class FlatGradAllReduce:
         return self.flat
 
     def all_reduce(self, average=False):
-        """wait for the bucket all-reduces started during backward()"""
+        """wait for the bucket all-reduces started during backward() (with RCCL, wait() orders the CURRENT stream after
+        the communication stream; the host does not block)"""
+        import time
+        t0 = time.perf_counter()
+        ev = None
+        if self.time_wait_events and self._pending and self.flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in self._pending:
             w.wait()
+        if ev is not None:
+            ev[1].record()
+            self.wait_events.append(ev)
         self._pending = []
+        self.stats["allreduce_wait_host_s"] += time.perf_counter() - t0
+        self.stats["allreduce_calls"] += 1
         if average and self._world() > 1:
             self.flat.div_(self._world())
         return self.flat

@@ -146,6 +146,56 @@ def test_gloo_world2_bench_rank_code_path():
     assert "GLOO_BENCH_OK" in p.stdout
 
 
+def test_gloo_world8_bench_rank_code_path():
+    """the same rank path with EIGHT ranks (the driver's 8-GPU run cannot be rehearsed on hardware here): rendezvous,
+    disjoint CPU slices from pin_rank, shard_range over a global batch of 8 clouds, run_timed's barriers, per-rank times
+    gathered, MAX over ranks, replicas identical after the steps (tiny plan: one 256-point block per rank)"""
+    script = os.path.join(ROOT, "tests", "_gloo_bench_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", OMP_NUM_THREADS="1", GLOO_BENCH_WORLD="8")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                        "--master-addr", "127.0.0.1", "--master-port", "29537", script],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "GLOO_BENCH_OK" in p.stdout
+
+
+def test_bucket_collective_sees_the_concatenated_gradients():
+    """the bucket's all-reduce is issued right behind its concatenation, from the hook that completed the bucket: a stand-in
+    collective (same call contract as dist.all_reduce) must find the flat bucket already holding this step's gradients —
+    and its result (here: x 3, 'three identical replicas') is what the optimiser sees after all_reduce()"""
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(n)) for n in (5, 300, 7, 1000, 3)]
+    seen = []
+
+    class _Work:
+        def __init__(self, view):
+            self.view = view
+
+        def wait(self):
+            self.view.mul_(3.0)
+
+    def collective(view):
+        seen.append(view.clone())
+        return _Work(view)
+
+    flat = hdist.FlatGradAllReduce(ps, bucket_bytes=1024, collective=collective)
+    assert len(flat.buckets) >= 2
+    x = torch.randn(1000)
+    loss = sum((p * x[:p.numel()]).sum() * (i + 1) for i, p in enumerate(ps))
+    flat.backward(loss)
+    want = torch.cat([x[:p.numel()] * (i + 1) for i, p in enumerate(ps)])
+    # every collective call saw its bucket's finished concatenation (buckets complete in reverse order)
+    got = {}
+    for v in seen:
+        for (i0, i1, f0, f1) in flat.buckets:
+            if v.numel() == f1 - f0 and torch.equal(v, want[f0:f1]):
+                got[(f0, f1)] = True
+    assert len(got) == len(flat.buckets)
+    flat.all_reduce()
+    torch.testing.assert_close(flat.flat, 3.0 * want)
+    assert flat.stats["buckets_started_in_backward"] == len(flat.buckets)
+
+
 def test_modelnet_small_net_on_oracle_ops():
     """SPH3D_modelnet call pattern (BASELINE config #1): 1024 points, raw-xyz concatenation (odd channel
     counts 35 / 67), per-level global max-pools, global conv with K = remaining points and 17 bins, fc + dropout."""

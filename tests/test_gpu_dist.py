@@ -36,3 +36,52 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     r = out["roofline"]
     assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and r["isolated_us"] and "family" in r
     assert out["steps"] == 3 and out["n_gpus"] == 1 and out["config"]["resident_batches"] == 2
+
+
+def test_bucket_collective_is_ordered_after_the_concatenation_on_a_side_stream(dev):
+    """the backward pass of the bench step does not run on the default stream.  ProcessGroupNCCL (= RCCL)
+    orders its communication stream after an event recorded on the CURRENT stream at the all_reduce call; FlatGradAllReduce
+    relies on that by issuing the bucket's concatenation on the current stream and the collective right behind it.  A
+    stand-in collective with exactly that contract (event on the current stream -> wait on a private stream -> work there ->
+    .wait() orders the current stream after it) must therefore see complete buckets when forward and backward run on a
+    non-default stream with long-running kernels queued in front."""
+    import torch
+    from sph3d_gcn_amd.harness import dist as hdist
+    comm = torch.cuda.Stream(device=dev)
+    side = torch.cuda.Stream(device=dev)
+
+    class _Work:
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+
+    def collective(view):
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        comm.wait_event(ready)
+        with torch.cuda.stream(comm):
+            view.mul_(2.0)                           # "sum over two identical replicas"
+            done = torch.cuda.Event()
+            done.record(comm)
+        return _Work(done)
+
+    torch.manual_seed(1)
+    ps = [torch.nn.Parameter(torch.randn(n, device=dev)) for n in (1 << 20, 3, 1 << 21, 17, 1 << 20)]
+    flat = hdist.FlatGradAllReduce(ps, bucket_bytes=4 << 20, collective=collective)
+    assert len(flat.buckets) >= 2
+    x = torch.randn(1 << 21, device=dev)
+    big = torch.randn(4096, 4096, device=dev)
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                big = (big @ big).clamp_(-1, 1)      # keeps the side stream busy in front of the step
+            loss = sum((p * x[:p.numel()]).sum() * (i + 1) for i, p in enumerate(ps))
+            flat.backward(loss)
+            flat.all_reduce()
+            got = flat.flat.clone()
+        side.synchronize()
+        want = 2.0 * torch.cat([x[:p.numel()] * (i + 1) for i, p in enumerate(ps)])
+        torch.testing.assert_close(got, want)
+    assert flat.stats["buckets_started_in_backward"] == 3 * len(flat.buckets)
