@@ -337,6 +337,140 @@ def _self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def event_families(events, ev_steps):
+    """per-call device times of the event pass -> (per-call table, family table, top kernels)"""
+    per = {}
+    for name, ints, e0, e1 in events:
+        d = per.setdefault((name, ints), [0.0, 0])
+        d[0] += e0.elapsed_time(e1)
+        d[1] += 1
+    fam = {}
+    for (name, ints), (ms, cnt) in per.items():
+        f = "sph3d_pointwise_gemm*" if "gemm" in name else name
+        fam[f] = fam.get(f, 0.0) + ms
+    families = {k: round(v / ev_steps, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])}
+    kernels = []
+    for (name, ints), (ms, cnt) in sorted(per.items(), key=lambda kv: -kv[1][0])[:8]:
+        kernels.append({"op": name, "dims": list(ints[:7]), "calls_per_step": cnt / ev_steps,
+                        "avg_us": round(ms / cnt * 1e3, 1), "ms_per_step": round(ms / ev_steps, 3)})
+    return per, families, kernels
+
+
+def secondary_main(args, rank, world, dev, pinned_cpus):
+    """BASELINE configs 2, 3 and 5 on the same harness and contract as the headline (SECONDARY lines: `metric` names the
+    config; BASELINE.json's own metric is the s3dis line).  A step = graph construction + forward + loss + backward +
+    gradient all-reduce (N > 1) + Adam on one resident synthetic batch; two batches alternate."""
+    from sph3d_gcn_amd.harness import modelnet_net, shapenet_net
+    name = args.config
+    rng = np.random.RandomState(17 + rank)
+    if name == "modelnet":
+        per_gpu, npts = 32, 10000
+        cfg = modelnet_net.modelnet_config(npts)
+        model = modelnet_net.SPH3DModelNet(cfg, device=dev)
+        batches = [(torch.from_numpy(synth.modelnet_batch(1000 + (w * 64 + rank) * per_gpu, per_gpu, npts)).to(dev),
+                    torch.from_numpy(rng.randint(0, 40, (per_gpu,))).to(dev)) for w in range(NUM_BATCHES)]
+        fwd = lambda b: model.loss(model(b[0], is_training=True)[0], b[1])
+        metric = "point clouds/sec (fwd+bwd) SPH3D_modelnet 10000-pt"
+        workload = ("SPH3D_modelnet cls net (modelnet_config.py plan, 788 396 parameters), ModelNet-like 10000-pt clouds, "
+                    "%d clouds/GPU, graph build + fwd + bwd + Adam" % per_gpu)
+    elif name == "shapenet":
+        per_gpu, npts = 64, 2048
+        cfg = shapenet_net.shapenet_config(npts)
+        model = shapenet_net.SPH3DShapeNet(3, cfg, device=dev)
+        batches = [(torch.from_numpy(synth.modelnet_batch(5000 + (w * 64 + rank) * per_gpu, per_gpu, npts)).to(dev),
+                    torch.from_numpy(rng.randint(0, 3, (per_gpu, npts))).to(dev)) for w in range(NUM_BATCHES)]
+        fwd = lambda b: model.loss(model(b[0], is_training=True)[0], b[1])
+        metric = "point clouds/sec (fwd+bwd) SPH3D_shapenet 2048-pt"
+        workload = ("SPH3D_shapenet part-seg net (shapenet_config.py plan, category Table: 3 parts), 2048-pt objects, "
+                    "%d objects/GPU, graph build + fwd + bwd + Adam" % per_gpu)
+    else:
+        per_gpu, npts = 1, 65536
+        cfg = s3dis_net.scannet_config(npts)
+        model = s3dis_net.SPH3DS3DIS(cfg, device=dev)
+        batches = []
+        for w in range(NUM_BATCHES):
+            xyz, label, inner = synth.s3dis_batch(7000 + w * 64 + rank, per_gpu, npts, extent=(6.0, 6.0, 3.0))
+            pts = np.concatenate([xyz, rng.rand(per_gpu, npts, 6).astype(np.float32)], axis=2)
+            batches.append((torch.from_numpy(pts).to(dev), torch.from_numpy(rng.randint(0, cfg.num_cls, (per_gpu, npts))).to(dev),
+                            torch.from_numpy(inner).to(dev)))
+        fwd = lambda b: model.loss(model(b[0], is_training=True)[0], b[1], b[2])
+        metric = "point-cloud blocks/sec (fwd+bwd) SPH3D seg net 65536-pt"
+        workload = ("SPH3D_s3dis plan with ScanNet's 21 classes on 65536-pt blocks (sample counts x8: 16384/6144/3072/1024), "
+                    "K = 64, reference radius semantics, %d block/GPU, graph build + fwd + bwd + Adam" % per_gpu)
+    torch.cuda.synchronize()
+    fwd(batches[0]).backward()                                   # creates the variables
+    flat = hdist.FlatGradAllReduce(model.parameters())
+    flat.broadcast_params(0)
+    opt = hoptim.FlatAdam(flat.flat_param, lr=1e-3, eps=1e-4)
+    step_no = [0]
+
+    def one_step():
+        b = batches[step_no[0] % NUM_BATCHES]
+        step_no[0] += 1
+        loss = fwd(b)
+        flat.backward(loss)
+        flat.all_reduce()
+        opt.step()
+        return loss
+
+    for _ in range(PRIME_STEPS):
+        one_step()
+    torch.cuda.synchronize()
+    elapsed, loss = run_timed(one_step, args.steps, args.warmup, world, torch.cuda.synchronize)
+    ev_steps = min(args.steps, 10)
+    _lib.timing_start()
+    for _ in range(ev_steps):
+        one_step()
+    torch.cuda.synchronize()
+    events = _lib.timing_stop()
+    per_rank_s = hdist.gather_floats(elapsed, world, dev)
+    elapsed = reduce_max_seconds(elapsed, world, dev)
+    per, families, kernels = event_families(events, ev_steps)
+    # roofline object of the dominant family's largest call (same rules as the headline line)
+    roofline = None
+    if families:
+        # (the sampling chain runs on a side stream and is latency-bound: it is in `families`, not the roofline kernel)
+        fname = next(k for k in families if k != "sph3d_farthest_point_sample")
+        best = None
+        for (cname, ints), (ms, cnt) in per.items():
+            if ("sph3d_pointwise_gemm*" if "gemm" in cname else cname) != fname:
+                continue
+            work = 2.0 * ints[0] * ints[1] * ints[2] if "gemm" in cname else float(algorithmic_bytes(cname, ints))
+            if best is None or work > best[0]:
+                best = (work, cname, ints, ms / cnt / 1e3)
+        if best is not None and best[0] > 0:
+            work, cname, ints, avg_s = best
+            gemm = "gemm" in cname
+            peak = FP32_MFMA_PEAK_TFLOPS if gemm else HBM_PEAK_GBS
+            ach = work / (1e12 if gemm else 1e9) / avg_s
+            roofline = {"kernel": cname, "family": fname, "dims": list(ints[:7]), "bound": "mfma" if gemm else "hbm",
+                        "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s" if gemm else "GB/s", "frac": round(ach / peak, 4),
+                        "avg_us": round(avg_s * 1e6, 1), "traffic": None,
+                        "family_ms_per_step": families[fname],
+                        "note": "avg_us: HIP events around the C-ABI call inside the running step; no PMC pass for this config"}
+    if rank == 0:
+        units = world * per_gpu * args.steps
+        out = {"metric": metric, "value": round(units / elapsed, 3), "unit": "clouds/s" if name != "scannet" else "blocks/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "secondary": True,
+               "config": {"workload": workload, "global_batch": world * per_gpu, "points_per_cloud": npts,
+                          "parallelism": "dp%d (one cloud shard per GPU; flat gradient all-reduced over RCCL in %d buckets)"
+                                         % (world, len(flat.buckets)),
+                          "resident_batches": NUM_BATCHES, "params": flat.num_parameters, "launch_mode": "eager",
+                          "atan2": args.atan2, "conv_forward": args.conv,
+                          "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                          "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
+                          "cpus_per_rank": pinned_cpus},
+               "dist": {"per_rank_ms_per_step": [round(x / args.steps * 1e3, 3) for x in per_rank_s]},
+               "loss": round(float(loss), 5), "families_ms_per_step": families, "roofline": roofline, "kernels": kernels,
+               "cpu_baseline": None}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -347,6 +481,9 @@ def main():
                     help="angle function of the spherical-kernel binning: 'ocml' = ROCm's device-library atan2f, the function the "
                          "reference's own kernel calls when built for this GPU (bins bit-identical to the reference build); "
                          "'shared' = the correctly rounded atan2f shared with the CPU oracle")
+    ap.add_argument("--config", choices=("s3dis", "modelnet", "shapenet", "scannet"), default="s3dis",
+                    help="workload: 's3dis' = the headline (BASELINE.json's metric); the others are SECONDARY lines for BASELINE "
+                         "configs 2, 3 and 5 with the same JSON contract (per-GPU batch 32 / 64 / 1, weak scaling)")
     ap.add_argument("--conv", choices=("gather", "lds"), default="gather",
                     help="depthwise forward kernel: 'gather' (conv3d.hip) or 'lds' (convlds.hip: LDS tiles + per-graph plan)")
     args = ap.parse_args()
@@ -365,6 +502,8 @@ def main():
     from sph3d_gcn_amd import tf_buildkernel, _plan
     tf_buildkernel.set_atan2(args.atan2)          # reaches the fused graph kernel too (tf_nnquery.build_sphere_graph)
     _plan.set_mode(args.conv)
+    if args.config != "s3dis":
+        return secondary_main(args, rank, world, dev, pinned_cpus)
 
     batches = [make_batch(rank, dev, w) for w in range(NUM_BATCHES)]
     torch.cuda.synchronize()
@@ -383,7 +522,7 @@ def main():
     flat.broadcast_params(0)
     # train_s3dis.py:224 (epsilon=1e-4); one fused kernel over the flat parameter buffer instead of the foreach chain
     opt = hoptim.FlatAdam(flat.flat_param, lr=1e-3, eps=1e-4)        # one streaming kernel, torch.optim.Adam's arithmetic
-    nparams = flat.flat_param.numel()
+    nparams = flat.num_parameters
 
     # (launch mode: eager on three HIP streams.  A HIP-graph replay of the whole step does capture once every autograd node lives
     #  on a non-default stream (tools/exp_capture.py, round 3) and buys nothing: the feature path replays in 7.46 ms against 7.46

@@ -120,7 +120,10 @@ class FlatGradAllReduce:
         self.time_wait_events = False          # record a HIP-event pair around the wait in all_reduce() (bench.py's event pass)
         self.wait_events = []
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
+        # every parameter starts on a 16-byte boundary of the flat buffers (the HIP kernels take 16-byte vector loads of their
+        # operands: the ModelNet plan's odd channel counts would otherwise leave later weights 8-byte aligned); the padding
+        # elements stay zero in both buffers
+        n = sum((p.numel() + 3) // 4 * 4 for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_param = torch.nn.Parameter(torch.empty(n, dtype=torch.float32, device=dev))
@@ -129,15 +132,19 @@ class FlatGradAllReduce:
         self.buckets = []                      # (first param index, one past last, flat begin, flat end)
         b_first, b_off = 0, 0
         with torch.no_grad():
+            self.flat_param.data.zero_()
+            self._slots = []                   # (flat begin, numel) of every parameter
             for i, p in enumerate(self.params):
                 k = p.numel()
                 self.flat_param.data[off:off + k].copy_(p.data.reshape(-1))
                 p.data = self.flat_param.data[off:off + k].view_as(p)
                 p.grad = None
-                off += k
+                self._slots.append((off, k))
+                off += (k + 3) // 4 * 4
                 if (off - b_off) * 4 >= bucket_bytes or i == len(self.params) - 1:
                     self.buckets.append((b_first, i + 1, b_off, off))
                     b_first, b_off = i + 1, off
+        self._zero_pad = torch.zeros(4, dtype=torch.float32, device=dev)
         self._pending = []
         self._done = set()
         self._got = [dict() for _ in self.buckets]        # per bucket: parameter index -> gradient of this backward pass
@@ -149,9 +156,23 @@ class FlatGradAllReduce:
     def _world(self):
         return dist.get_world_size() if dist.is_initialized() else 1
 
+    @property
+    def num_parameters(self):
+        """parameter elements (the flat buffers also hold the alignment padding)"""
+        return sum(k for _off, k in self._slots)
+
+    def unpadded(self, flat):
+        """the parameters' elements of a flat buffer, in order, without the alignment padding"""
+        return torch.cat([flat[o:o + k] for o, k in self._slots])
+
     def _finish_bucket(self, bi, grads):
         i0, i1, f0, f1 = self.buckets[bi]
-        parts = [(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(grads, self.params[i0:i1])]
+        parts = []
+        for j, (g, p) in enumerate(zip(grads, self.params[i0:i1])):
+            parts.append((g if g is not None else torch.zeros_like(p)).reshape(-1))
+            pad = (-p.numel()) % 4
+            if pad:
+                parts.append(self._zero_pad[:pad])
         view = self.flat[f0:f1]
         # ORDER: the concatenation is issued on the CURRENT stream — inside a tensor hook that is the stream of the backward
         # node that produced the bucket's last gradient — and the collective is started right behind it from the same

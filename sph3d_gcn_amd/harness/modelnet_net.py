@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import sph3gcn_util as s3g_util
-from .s3dis_net import _separable_conv3d_block
+from .s3dis_net import GraphPlan, _separable_conv3d_block
 
 
 def modelnet_config(num_input=10000):
@@ -70,6 +70,12 @@ def get_model(points, is_training, config=None, dropout_generator=None):
     xyz = points
     query = xyz.mean(dim=1, keepdim=True)                   # the global viewing point
     reuse = None
+    # On the GPU the graph construction (same ops, arguments and results as the build_graph / spherical_kernel calls below) is
+    # issued ahead of the feature path on the sampling and graph streams, like the segmentation nets' (s3dis_net.GraphPlan)
+    plan = None
+    if xyz.is_cuda and config.sample == 'FPS':
+        plan = GraphPlan(xyz.contiguous(), config, decoder=False, global_kernel=[8, 2, 1], global_query=query,
+                         prepare_input=False)
     net = s3g_util.pointwise_conv3d(xyz, config.mlp, 'mlp1', weight_decay=config.weight_decay,
                                     with_bn=config.with_bn, with_bias=config.with_bias, reuse=reuse,
                                     is_training=is_training)
@@ -77,25 +83,39 @@ def get_model(points, is_training, config=None, dropout_generator=None):
     for l in range(len(config.radius)):
         if config.use_raw:
             net = torch.cat([net, xyz], dim=-1)
-        intra_idx, intra_cnt, intra_dst, indices = s3g_util.build_graph(
-            xyz, config.radius[l], config.nn_uplimit[l], config.num_sample[l], sample_method=config.sample)
-        filt_idx = s3g_util.spherical_kernel(xyz, xyz, intra_idx, intra_cnt, intra_dst, config.radius[l],
-                                             kernel=config.kernel)
+        if plan is not None:
+            g = plan.enc(l)
+            intra_idx, intra_cnt, filt_idx = g["intra_idx"], g["intra_cnt"], g["filt_idx"]
+            xyz = plan.xyz_layers[l]
+        else:
+            intra_idx, intra_cnt, intra_dst, indices = s3g_util.build_graph(
+                xyz, config.radius[l], config.nn_uplimit[l], config.num_sample[l], sample_method=config.sample)
+            filt_idx = s3g_util.spherical_kernel(xyz, xyz, intra_idx, intra_cnt, intra_dst, config.radius[l],
+                                                 kernel=config.kernel)
         net = _separable_conv3d_block(net, config.channels[l], config.binSize, intra_idx, intra_cnt, filt_idx,
                                       'conv' + str(l + 1), config.multiplier[l], reuse=reuse,
                                       weight_decay=config.weight_decay, with_bn=config.with_bn,
                                       with_bias=config.with_bias, is_training=is_training)
         if config.num_sample[l] > 1:
-            xyz = s3g_util.gather_nd(xyz, indices)
-            inter_idx = s3g_util.gather_nd(intra_idx, indices)
-            inter_cnt = s3g_util.gather_nd(intra_cnt, indices)
+            if plan is not None:
+                g = plan.pool(l)
+                inter_idx, inter_cnt = g["inter_idx"], g["inter_cnt"]
+                xyz = plan.xyz_layers[l + 1]
+            else:
+                xyz = s3g_util.gather_nd(xyz, indices)
+                inter_idx = s3g_util.gather_nd(intra_idx, indices)
+                inter_cnt = s3g_util.gather_nd(intra_cnt, indices)
             net = s3g_util.pool3d(net, inter_idx, inter_cnt, method=config.pool_method, scope='pool' + str(l + 1))
         global_feat.append(net.max(dim=1, keepdim=True)[0])
 
     # global feature extraction in the final layer (:83-93)
     global_radius = 100.0
-    nn_idx, nn_cnt, nn_dst = s3g_util.build_global_graph(xyz, query, global_radius)
-    filt_idx = s3g_util.spherical_kernel(xyz, query, nn_idx, nn_cnt, nn_dst, global_radius, kernel=[8, 2, 1])
+    if plan is not None:
+        g = plan.glob()
+        nn_idx, nn_cnt, filt_idx = g["nn_idx"], g["nn_cnt"], g["filt_idx"]
+    else:
+        nn_idx, nn_cnt, nn_dst = s3g_util.build_global_graph(xyz, query, global_radius)
+        filt_idx = s3g_util.spherical_kernel(xyz, query, nn_idx, nn_cnt, nn_dst, global_radius, kernel=[8, 2, 1])
     net = s3g_util.separable_conv3d(net, config.global_channels, 17, config.global_multiplier, 'global_conv', nn_idx,
                                     nn_cnt, filt_idx, reuse=reuse, weight_decay=config.weight_decay,
                                     with_bn=config.with_bn, with_bias=config.with_bias, is_training=is_training)

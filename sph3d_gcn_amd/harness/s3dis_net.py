@@ -36,6 +36,15 @@ def s3dis_config(num_input=8192):
     return c
 
 
+def scannet_config(num_input=65536):
+    """scannet_seg/scannet_config.py is the S3DIS plan with 21 classes at 8192 points; BASELINE config 5 asks for 65 536-point
+    blocks: the sample counts scale with the input (x8)"""
+    c = s3dis_config(num_input)
+    c.num_cls = 21
+    c.num_sample = [num_input // 4, num_input * 3 // 32, num_input * 3 // 64, num_input // 64]
+    return c
+
+
 def small_config(num_input=1024):
     """Reduced plan for smoke / CPU-oracle plumbing (BASELINE config #1 flavour)."""
     c = s3dis_config(num_input)
@@ -89,12 +98,20 @@ class GraphPlan:
     and the main stream waits, per level, only on the event of the graph it is about to use.
     On CPU tensors (oracle-backed tests) everything is built lazily on the spot."""
 
-    def __init__(self, points, config, overlap=True, points_ready=None):
-        """points_ready: optional event after which `points` is valid.  With it the two side streams wait only for the
+    def __init__(self, points, config, overlap=True, points_ready=None, decoder=True, global_kernel=None, global_radius=100.0,
+                 global_query=None, prepare_input=True):
+        """decoder=False: an encoder-only plan (the classification net); global_kernel: also the global graph of
+        models/SPH3D_modelnet.py:83-93 (query = centroid of the last level's points, every remaining point a neighbour) with
+        the bins of that kernel (global_query: the query points [B, 1, 3], default the centroid of the last level);
+        prepare_input=False: `points` are coordinates only (no S3DIS input features to prepare).
+        points_ready: optional event after which `points` is valid.  With it the two side streams wait only for the
         INPUT, not for everything queued on the main stream — so when the host runs ahead (it issues a step in about
         half the time the GPU needs), the sampling / graph construction of step t+1 overlaps the backward pass of step
         t instead of idling the main stream at every step boundary (measured: 5.8 ms of main-stream idle per step)."""
         self.config = config
+        self.decoder = bool(decoder)
+        self.global_kernel, self.global_radius, self.global_query = global_kernel, float(global_radius), global_query
+        self._glob, self._glob_ev = None, None
         xyz = points[:, :, 0:3]
         self.use_side = bool(overlap and xyz.is_cuda)
         self.xyz_layers, self.indices, self.events = [xyz], [], []
@@ -126,6 +143,12 @@ class GraphPlan:
             else:
                 s_fps.wait_stream(self.main)
                 s_graph.wait_stream(self.main)
+            # tensors made on the main stream and read by the side streams' kernels (a temporary such as the classification
+            # net's normalised coordinates may be freed by the caller while those kernels are still queued)
+            points.record_stream(s_fps)
+            points.record_stream(s_graph)
+            if global_query is not None:
+                global_query.record_stream(s_graph)
             with torch.cuda.stream(s_fps):
                 # one contiguous copy of the coordinates for every op of the plan (the [:, :, 0:3] view made each
                 # neighbour search / binning / sampling call copy it again)
@@ -135,10 +158,11 @@ class GraphPlan:
                 ev_xyz.record(s_fps)
                 # the network's input features (centred coordinates + colours, models/SPH3D_s3dis.py:11-19,38-41) depend on the
                 # batch only: prepared here, ahead of the feature path (one reduction + four small kernels, 60 us of main-stream time)
-                self.net_input = _net_input(points, config)
-                self._in_key = (points.data_ptr(), points._version, tuple(points.shape))
-                self._in_ev = torch.cuda.Event()
-                self._in_ev.record(s_fps)
+                if prepare_input:
+                    self.net_input = _net_input(points, config)
+                    self._in_key = (points.data_ptr(), points._version, tuple(points.shape))
+                    self._in_ev = torch.cuda.Event()
+                    self._in_ev.record(s_fps)
                 self._sampling_chain(s_fps)
             s_graph.wait_event(ev_xyz)
             # every tensor the sampling stream allocated is read by kernels on the graph stream (neighbour search,
@@ -235,6 +259,8 @@ class GraphPlan:
             table[key] = ev
 
         def make_dec(l):
+            if not self.decoder:
+                return
             g = self._make_dec(l)
             n_c = self.xyz_layers[L - l].shape[1]
             self._pretranspose(g, n_c, n_src_unpool=n_c)
@@ -256,6 +282,25 @@ class GraphPlan:
                 self._enc[s + 1] = g
                 mark(self._enc_ev, s + 1)
             make_dec(L - 1 - s)                  # needs point sets s+1 and s
+        if self.global_kernel is not None:
+            self._glob = self._make_global()
+            self._glob_ev = torch.cuda.Event()
+            self._glob_ev.record(stream)
+
+    def _make_global(self):
+        """models/SPH3D_modelnet.py:83-93: one query per cloud (the centroid of the level's points), every point a neighbour"""
+        xyz = self.xyz_layers[-1]
+        query = self.global_query if self.global_query is not None else xyz.mean(dim=1, keepdim=True)
+        nn_idx, nn_cnt, nn_dst = s3g_util.build_global_graph(xyz, query, self.global_radius)
+        filt = s3g_util.spherical_kernel(xyz, query, nn_idx, nn_cnt, nn_dst, self.global_radius, kernel=self.global_kernel)
+        return dict(nn_idx=nn_idx, nn_cnt=nn_cnt, filt_idx=filt, query=query)
+
+    def glob(self):
+        if self.use_side:
+            self._sync(("glob",), self._glob_ev, list(self._glob.values()) + [self.xyz_layers[-1]])
+        elif self._glob is None:
+            self._glob = self._make_global()
+        return self._glob
 
     def _sync(self, key, ev, tensors):
         if key in self._synced:
@@ -289,7 +334,7 @@ class GraphPlan:
         """rows of the level-l intra graph at the sampled points"""
         g = self.enc(l)
         if self.use_side:
-            self._sync(("pool", l), self._pool_ev[l], [g["inter_idx"], g["inter_cnt"]])
+            self._sync(("pool", l), self._pool_ev[l], [g["inter_idx"], g["inter_cnt"]] + self.xyz_layers[l + 1:l + 2])
         elif "inter_idx" not in g:
             self._make_pool(l, g)
         return g

@@ -183,7 +183,10 @@ def test_bucket_collective_sees_the_concatenated_gradients():
     x = torch.randn(1000)
     loss = sum((p * x[:p.numel()]).sum() * (i + 1) for i, p in enumerate(ps))
     flat.backward(loss)
-    want = torch.cat([x[:p.numel()] * (i + 1) for i, p in enumerate(ps)])
+    want = torch.zeros_like(flat.flat)               # parameters start on 16-byte boundaries of the flat buffer: padding stays 0
+    for (o, k), (i, p) in zip(flat._slots, enumerate(ps)):
+        want[o:o + k] = x[:k] * (i + 1)
+        assert o % 4 == 0
     # every collective call saw its bucket's finished concatenation (buckets complete in reverse order)
     got = {}
     for v in seen:

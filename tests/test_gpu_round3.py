@@ -152,13 +152,7 @@ def test_conv_gradient_65_bins(dev, C, r, nbins):
     np.testing.assert_allclose(_n(out), oracle.depthwise_conv3d(x, w, idx, cnt, filt), **TOL)
 
 
-def scannet_config(num_input=65536):
-    """scannet_seg/scannet_config.py is the S3DIS plan with 21 classes at 8192 points; BASELINE config 5 asks for 65 536-point
-    blocks: the sample counts scale with the input (x8)"""
-    c = s3dis_net.s3dis_config(num_input)
-    c.num_cls = 21
-    c.num_sample = [16384, 6144, 3072, 1024]
-    return c
+scannet_config = s3dis_net.scannet_config
 
 
 @pytest.mark.parametrize("mode", ["compat", "fixed"])
