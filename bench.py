@@ -356,6 +356,63 @@ def event_families(events, ev_steps):
     return per, families, kernels
 
 
+def eval_main(args, rank, world, dev, pinned_cpus):
+    """forward-only secondary line of the headline workload: graph construction + inference forward of the S3DIS net on 16
+    resident blocks per GPU, batch-norm moving statistics, every separable layer as one kernel"""
+    from sph3d_gcn_amd import sph3gcn_util as s3g_util
+    batches = [make_batch(rank, dev, w) for w in range(NUM_BATCHES)]
+    model = s3dis_net.SPH3DS3DIS(s3dis_net.s3dis_config(NUM_POINT), device=dev)
+    pred, _ = model(batches[0][0], is_training=True)            # creates the variables; one training step moves the statistics
+    model.loss(pred, batches[0][1], batches[0][2]).backward()
+    step_no = [0]
+
+    def one_step():
+        p_ = batches[step_no[0] % NUM_BATCHES][0]
+        step_no[0] += 1
+        with torch.no_grad():
+            return model(p_, is_training=False)[0]
+
+    for _ in range(PRIME_STEPS):
+        one_step()
+    torch.cuda.synchronize()
+    elapsed, pred = run_timed(one_step, args.steps, args.warmup, world, torch.cuda.synchronize)
+    ev_steps = min(args.steps, 10)
+    _lib.timing_start()
+    for _ in range(ev_steps):
+        one_step()
+    torch.cuda.synchronize()
+    events = _lib.timing_stop()
+    elapsed = reduce_max_seconds(elapsed, world, dev)
+    per, families, kernels = event_families(events, ev_steps)
+    # the same forward with the separable layers run kernel by kernel (depthwise -> GEMM -> affine), for the record
+    fuse_mode = s3g_util.FUSE_SEPARABLE_INFERENCE
+    s3g_util.FUSE_SEPARABLE_INFERENCE = False
+    try:
+        for _ in range(3):
+            one_step()
+        torch.cuda.synchronize()
+        t_unfused, _ = run_timed(one_step, min(args.steps, 10), 1, 1, torch.cuda.synchronize)
+        t_unfused /= min(args.steps, 10)
+    finally:
+        s3g_util.FUSE_SEPARABLE_INFERENCE = fuse_mode
+    if rank == 0:
+        out = {"metric": "point-cloud blocks/sec (inference) SPH3D_s3dis 8192-pt", "value": round(world * BLOCKS_PER_GPU * args.steps / elapsed, 3),
+               "unit": "blocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic", "secondary": True,
+               "config": {"workload": "SPH3D_s3dis seg net, forward only (is_training=False, no_grad), S3DIS-like 8192-pt blocks, %d "
+                                      "blocks/GPU, graph build + forward; separable layers as one kernel where that is the faster "
+                                      "form (FUSE_SEPARABLE_INFERENCE = %r)" % (BLOCKS_PER_GPU, fuse_mode),
+                          "global_batch": world * BLOCKS_PER_GPU, "points_per_block": NUM_POINT, "atan2": args.atan2,
+                          "parallelism": "dp%d (replicas, no collective)" % world, "cpus_per_rank": pinned_cpus},
+               "ms_per_step_layer_by_layer": round(t_unfused * 1e3, 3),
+               "families_ms_per_step": families, "kernels": kernels, "roofline": None, "cpu_baseline": None}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def secondary_main(args, rank, world, dev, pinned_cpus):
     """BASELINE configs 2, 3 and 5 on the same harness and contract as the headline (SECONDARY lines: `metric` names the
     config; BASELINE.json's own metric is the s3dis line).  A step = graph construction + forward + loss + backward +
@@ -484,6 +541,9 @@ def main():
     ap.add_argument("--config", choices=("s3dis", "modelnet", "shapenet", "scannet"), default="s3dis",
                     help="workload: 's3dis' = the headline (BASELINE.json's metric); the others are SECONDARY lines for BASELINE "
                          "configs 2, 3 and 5 with the same JSON contract (per-GPU batch 32 / 64 / 1, weak scaling)")
+    ap.add_argument("--eval", action="store_true",
+                    help="SECONDARY line: forward only (is_training=False under no_grad: every separable layer is ONE kernel, "
+                         "csrc/sepconv.hip) on the headline's batch; metric 'point-cloud blocks/sec (inference)'")
     ap.add_argument("--conv", choices=("gather", "lds"), default="gather",
                     help="depthwise forward kernel: 'gather' (conv3d.hip) or 'lds' (convlds.hip: LDS tiles + per-graph plan)")
     args = ap.parse_args()
@@ -504,6 +564,8 @@ def main():
     _plan.set_mode(args.conv)
     if args.config != "s3dis":
         return secondary_main(args, rank, world, dev, pinned_cpus)
+    if args.eval:
+        return eval_main(args, rank, world, dev, pinned_cpus)
 
     batches = [make_batch(rank, dev, w) for w in range(NUM_BATCHES)]
     torch.cuda.synchronize()

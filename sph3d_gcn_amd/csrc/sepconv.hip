@@ -9,7 +9,8 @@
 // weights on the matrix cores — v_mfma_f32_16x16x4_f32, one 16 x 16 output block per wave, its 16 columns of W
 // (C*r x 16 floats = 64 VGPRs at C*r = 256) RESIDENT IN REGISTERS for the whole launch — and apply the epilogue.
 // In training the depthwise tensor is the weight gradient's operand and has to be written anyway, so this
-// path is taken when no gradient is recorded; shapes outside C <= 128, C*r <= 256, Cout <= 128 use the separate kernels.
+// path is taken when no gradient is recorded.  Shapes outside C <= 128, C*r <= 256, Cout <= 128 — every deeper layer of the
+// S3DIS / ShapeNet plans — run sepconv_general_kernel below (accumulators resident, W streamed per k slice).
 //
 // k-order of the product: lane (i = lane % 16, kq = lane / 16) supplies A[i][16t + 4kq + u] and B[16t + 4kq + u][j] at step
 // (t, u): any pairing is legal as long as A and B use the same one, and this one makes a lane's four A values of a t ONE
@@ -207,6 +208,236 @@ __global__ __launch_bounds__(1024) void sepconv_fused_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// General shapes (round 4): any layer of the S3DIS / ShapeNet plans (C up to 1024 in slices of 128 input channels, Cout up to
+// 512).  The pointwise weights no longer fit a wave's registers (C*r x Cout = up to 2048 x 512 floats), so the product is
+// organised the other way round: the ACCUMULATORS stay resident — wave w owns the output column blocks cb = w, w + 16 of a
+// tile of TP = 16 * RBK points (RBK x 2 blocks of 16 x 16: <= 32 VGPRs) across the whole k range — and the layer is walked
+// slice by slice: filter slice -> LDS, the 16 waves gather the slice's depthwise outputs of the tile's points into the
+// LDS A tile [TP][SLI*R] (same gather as above), then every wave multiplies the tile with ITS columns of the slice's
+// k-rows of W, fetched from global memory / L2 as they are needed (a lane's four B values of a t are four 4-byte loads of
+// 16 consecutive columns; each fragment feeds RBK row blocks).  Per tile W is read once (C*r*Cout*4 B from L2): the kernel
+// trades the [B, M, C*r] depthwise tensor's HBM round trip (write + read) for L2 reads of W per tile.
+// ------------------------------------------------------------------------------------------------------------------
+template <int R, int LPE, int RBK>
+__global__ __launch_bounds__(1024) void sepconv_general_kernel(
+    int B, int N, int M, int F, int C, int K, int Cout, int act,
+    const int* __restrict__ nnIndex, const int* __restrict__ nnCount, const int* __restrict__ binIndex,
+    const float* __restrict__ input, const float* __restrict__ dwFilter, const float* __restrict__ W,
+    const float* __restrict__ bias, const float* __restrict__ scale, const float* __restrict__ shift,
+    float* __restrict__ output)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int EPL = 64 / LPE;
+    constexpr int NO = 4 * R;
+    constexpr int SLI = 4 * LPE;                 // input channels per slice
+    constexpr int FSTB = SLI * R * 4;            // bytes per filter row in LDS
+    constexpr int KP = SLI * R;                  // k extent of a slice
+    constexpr int KT = KP / 16;
+    constexpr int LDA = KP + 4;
+    constexpr int TP = 16 * RBK;                 // points per tile
+    constexpr int PPW = (TP + kScWaves - 1) / kScWaves;      // points a wave gathers per tile and slice
+    float* lfilt = lds;                                          // [F + 1][R][SLI]
+    float* atile = lds + (size_t)(F + 1) * SLI * R;              // [TP][LDA]
+    const int CR = C * R;
+    const int tid = (int)threadIdx.x;
+    const int wave = uniform(tid >> 6);
+    const int lane = lane_id();
+    const int nslices = (C + SLI - 1) / SLI;
+    const int ncb = Cout >> 4;                                   // <= 32
+    const int i16 = lane & 15, kq = lane >> 4;
+
+    const int tpc = (M + TP - 1) / TP;                           // tiles per cloud
+    const int WPX = (int)gridDim.x >> 3;
+    const int xcd = (int)blockIdx.x & 7, wi = (int)blockIdx.x >> 3;
+    const bool affine = (B & 7) == 0;
+    long long total, part, parts;
+    if (affine) { total = (long long)(B >> 3) * tpc; part = wi; parts = WPX; }
+    else { total = (long long)B * tpc; part = (long long)xcd * WPX + wi; parts = 8LL * WPX; }
+    const int f_begin = (int)(total * part / parts), f_end = (int)(total * (part + 1) / parts);
+
+    const int g = lane / LPE, li = lane - g * LPE;
+    const unsigned rowb = (unsigned)C * 4u;
+    const char* lfb = reinterpret_cast<const char*>(lfilt);
+    for (int e = tid; e < SLI * R; e += kScWaves * 64) lfilt[F * (SLI * R) + e] = 0.f;      // zero filter row of padding slots
+
+    int cl = f_begin / tpc, tl = f_begin - cl * tpc;
+    for (int it = f_begin; it < f_end; it++) {
+        const int b = affine ? xcd + 8 * cl : cl;
+        const int m0 = tl * TP;
+        sc_f32x4 d[2][RBK];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; c2++)
+#pragma unroll
+            for (int rb = 0; rb < RBK; rb++) d[c2][rb] = sc_f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < nslices; s++) {
+            const int c0 = s * SLI;
+            const int SLc = (C - c0) < SLI ? (C - c0) : SLI;             // channels of this slice (multiple of 4)
+            __syncthreads();                                              // the previous slice's product is done with LDS
+            // ---- filter slice -> LDS ----
+            for (int e = tid * 4; e < F * SLc * R; e += kScWaves * 64 * 4) {
+                const int f = e / (SLc * R);
+                const int cl4 = e - f * (SLc * R);
+                const int l4 = cl4 / (4 * R), q = (cl4 >> 2) % R;
+                *reinterpret_cast<float4*>(&lfilt[f * (SLI * R) + q * SLI + l4 * 4]) =
+                    *reinterpret_cast<const float4*>(&dwFilter[(size_t)f * CR + (size_t)c0 * R + cl4]);
+            }
+            __syncthreads();
+            // ---- gather: wave w takes points m0 + w + 16 h of the tile ----
+            const bool actl = li * 4 < SLc;
+            const unsigned cicb = (unsigned)(c0 + (actl ? li * 4 : 0)) * 4u;
+            const unsigned ficb = (unsigned)(actl ? li * 4 : 0) * 4u;
+            const char* inb = reinterpret_cast<const char*>(input + (size_t)b * N * C);
+#pragma unroll 1
+            for (int h = 0; h < PPW; h++) {
+                const int p = wave + kScWaves * h;
+                if (p >= TP) break;
+                const int m = m0 + p;
+                float acc[NO];
+#pragma unroll
+                for (int v = 0; v < NO; v++) acc[v] = 0.f;
+                int cnt = 0;
+                if (m < M) {
+                    const size_t row = (size_t)b * M + m;
+                    cnt = uniform(nnCount[row]);
+                    for (int kt = 0; kt < cnt; kt += 64) {
+                        const int myk = kt + lane;
+                        const int kn = (cnt - kt) < 64 ? (cnt - kt) : 64;
+                        const int mykc = myk < cnt ? myk : kt;
+                        const int idxv = nnIndex[row * K + mykc];
+                        int binv = binIndex[row * K + mykc];
+                        binv = binv < 0 ? 0 : (binv >= F ? F - 1 : binv);
+                        binv = myk < cnt ? binv : F;
+                        const unsigned pk = ((unsigned)idxv & 0xffffffu) | ((unsigned)binv << 24);
+                        for (int k0 = 0; k0 < kn; k0 += 4 * EPL) {
+                            float4 x[4];
+                            unsigned fo[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const int kq2 = k0 + u * EPL + g;
+                                const unsigned pp = (unsigned)__shfl((int)pk, kq2);
+                                const unsigned off = __umul24(pp, rowb) + cicb;
+                                fo[u] = __umul24(pp >> 24, (unsigned)FSTB) + ficb;
+                                x[u] = *reinterpret_cast<const float4*>(inb + off);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+#pragma unroll
+                                for (int q = 0; q < R; q++) {
+                                    const float4 w4 = *reinterpret_cast<const float4*>(lfb + fo[u] + q * (SLI * 4));
+                                    acc[4 * q + 0] = fmaf(xs[(4 * q + 0) / R], w4.x, acc[4 * q + 0]);
+                                    acc[4 * q + 1] = fmaf(xs[(4 * q + 1) / R], w4.y, acc[4 * q + 1]);
+                                    acc[4 * q + 2] = fmaf(xs[(4 * q + 2) / R], w4.z, acc[4 * q + 2]);
+                                    acc[4 * q + 3] = fmaf(xs[(4 * q + 3) / R], w4.w, acc[4 * q + 3]);
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = LPE; o < 64; o <<= 1)
+#pragma unroll
+                    for (int v = 0; v < NO; v++) acc[v] += __shfl_xor(acc[v], o);
+                if (g == 0) {
+                    // lanes beyond the slice's channels write zeros: k columns the product multiplies with W rows that do not exist
+                    const float inv = (cnt > 0 && actl) ? 1.0f / (float)cnt : 0.f;
+                    float* ap = atile + (size_t)p * LDA + li * 4 * R;
+#pragma unroll
+                    for (int q = 0; q < R; q++)
+                        *reinterpret_cast<float4*>(ap + 4 * q) =
+                            make_float4(acc[4 * q] * inv, acc[4 * q + 1] * inv, acc[4 * q + 2] * inv, acc[4 * q + 3] * inv);
+                }
+            }
+            __syncthreads();
+            // ---- product: this wave's column blocks x every row block of the tile, k rows of this slice ----
+            const int kbase = c0 * R;                                    // first k row of the slice in W
+#pragma unroll
+            for (int c2 = 0; c2 < 2; c2++) {
+                const int cb = wave + kScWaves * c2;
+                if (cb >= ncb) break;
+                const float* wp = W + (size_t)kbase * Cout + cb * 16 + i16;
+#pragma unroll 1
+                for (int t = 0; t < KT; t++) {
+                    float bw[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int k = 16 * t + 4 * kq + u;
+                        bw[u] = k < SLc * R ? wp[(size_t)k * Cout] : 0.f;
+                    }
+                    sc_f32x4 a[RBK];
+#pragma unroll
+                    for (int rb = 0; rb < RBK; rb++)
+                        a[rb] = *reinterpret_cast<const sc_f32x4*>(atile + (size_t)(rb * 16 + i16) * LDA + 16 * t + 4 * kq);
+                    // (u outer, row blocks inner: consecutive MFMAs write different accumulators)
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+#pragma unroll
+                        for (int rb = 0; rb < RBK; rb++)
+                            d[c2][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][u], bw[u], d[c2][rb], 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue: bias -> ELU -> per-channel affine; D layout: lane holds rows 4*(lane/16) + r of column lane % 16 ----
+#pragma unroll
+        for (int c2 = 0; c2 < 2; c2++) {
+            const int cb = wave + kScWaves * c2;
+            if (cb >= ncb) break;
+            const int col = cb * 16 + i16;
+            const float bv = bias != nullptr ? bias[col] : 0.f;
+            const float sc = scale != nullptr ? scale[col] : 1.f;
+            const float sh = shift != nullptr ? shift[col] : 0.f;
+#pragma unroll
+            for (int rb = 0; rb < RBK; rb++)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) {
+                    const int m = m0 + rb * 16 + 4 * kq + r4;
+                    if (m < M) {
+                        float y = d[c2][rb][r4] + bv;
+                        if (act == 1) y = sc_elu(y);
+                        output[((size_t)b * M + m) * Cout + col] = fmaf(y, sc, sh);
+                    }
+                }
+        }
+        if (++tl == tpc) { tl = 0; cl++; }
+    }
+}
+
+// shapes of the general kernel: C <= 128 (one, possibly partial, slice) or a multiple of 128; Cout a multiple of 16, <= 512
+static bool sc_general_ok(int N, int F, int C, int r, int K, int Cout)
+{
+    return (r == 1 || r == 2) && C % 4 == 0 && C >= 4 && (C <= 128 || (C % 128 == 0 && C <= 4096)) && Cout % 16 == 0 && Cout >= 16 &&
+           Cout <= 512 && F <= 254 && N <= (1 << 24) && K > 0 && (unsigned long long)N * C * 4ull + 1024ull < (1ull << 32);
+}
+
+template <int R, int LPE>
+static int sc_launch_general(int B, int N, int M, int F, int C, int K, int Cout, int act, const int* nn_index, const int* nn_count,
+                             const int* bin_index, const float* input, const float* dw_filter, const float* W, const float* bias,
+                             const float* scale, const float* shift, float* output, hipStream_t st)
+{
+    // tile height: as many row blocks as still leave every CU a tile
+    const long long pts = (long long)B * M;
+    const int rbk = pts >= 64LL * 512 ? 4 : (pts >= 32LL * 256 ? 2 : 1);
+    const size_t lds = sizeof(float) * ((size_t)(F + 1) * 4 * LPE * R + (size_t)(16 * rbk) * (4 * LPE * R + 4));
+    SPH3D_REQUIRE(lds <= 160 * 1024, "SeparableConv3dFused: %zu B of LDS needed", lds);
+#define SPH3D_SCG(RB)                                                                                                        \
+    {                                                                                                                        \
+        auto kern = sepconv_general_kernel<R, LPE, RB>;                                                                      \
+        if (lds > 48 * 1024) {                                                                                               \
+            int rc = check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), \
+                               "SeparableConv3dFused: hipFuncSetAttribute");                                                 \
+            if (rc) return rc;                                                                                               \
+        }                                                                                                                    \
+        hipLaunchKernelGGL(kern, dim3(256), dim3(1024), lds, st, B, N, M, F, C, K, Cout, act, nn_index, nn_count, bin_index, input, \
+                           dw_filter, W, bias, scale, shift, output);                                                        \
+    }
+    if (rbk == 4) SPH3D_SCG(4)
+    else if (rbk == 2) SPH3D_SCG(2)
+    else SPH3D_SCG(1)
+#undef SPH3D_SCG
+    return check_launch("sph3d_separable_conv3d_fused (general)");
+}
+
 static bool sc_shape_ok(int N, int F, int C, int r, int K, int Cout)
 {
     return (r == 1 || r == 2) && C % 4 == 0 && C >= 4 && C <= 128 && C * r <= 256 && Cout % 16 == 0 && Cout >= 16 && Cout <= 128 &&
@@ -246,7 +477,7 @@ using namespace sph3d;
 
 extern "C" int sph3d_separable_conv3d_fused_supported(int N, int F, int C, int r, int K, int Cout)
 {
-    return sc_shape_ok(N, F, C, r, K, Cout) ? 1 : 0;
+    return (sc_shape_ok(N, F, C, r, K, Cout) || sc_general_ok(N, F, C, r, K, Cout)) ? 1 : 0;
 }
 
 extern "C" int sph3d_separable_conv3d_fused(int B, int N, int M, int F, int C, int r, int K, int Cout, int act,
@@ -258,13 +489,26 @@ extern "C" int sph3d_separable_conv3d_fused(int B, int N, int M, int F, int C, i
     SPH3D_REQUIRE(B >= 0 && N > 0 && M >= 0 && F > 0 && C > 0 && K > 0 && Cout > 0,
                   "SeparableConv3dFused: bad dims B=%d N=%d M=%d F=%d C=%d K=%d Cout=%d", B, N, M, F, C, K, Cout);
     SPH3D_REQUIRE(act == 0 || act == 1, "SeparableConv3dFused: act must be 0 (none) or 1 (ELU), got %d", act);
-    if (!sc_shape_ok(N, F, C, r, K, Cout)) {
-        set_error("SeparableConv3dFused: shape C=%d r=%d Cout=%d F=%d not covered (C <= 128, C*r <= 256, Cout <= 128 in multiples of 16)",
-                  C, r, Cout, F);
+    const bool small = sc_shape_ok(N, F, C, r, K, Cout);
+    if (!small && !sc_general_ok(N, F, C, r, K, Cout)) {
+        set_error("SeparableConv3dFused: shape C=%d r=%d Cout=%d F=%d not covered (C %% 4 == 0 and C <= 128 or a multiple of 128; "
+                  "Cout <= 512 in multiples of 16; r in {1, 2})", C, r, Cout, F);
         return SPH3D_EUNSUPPORTED;
     }
     if (B == 0 || M == 0) return SPH3D_OK;
     hipStream_t st = as_stream(stream);
+    if (!small) {
+        // the layers whose pointwise weights do not fit a wave's registers: accumulators resident, W streamed per k slice
+        if (C <= 64)
+            return r == 2 ? sc_launch_general<2, 16>(B, N, M, F, C, K, Cout, act, nn_index, nn_count, bin_index, input, depthwise_filter,
+                                                     pointwise_weights, bias, scale, shift, output, st)
+                          : sc_launch_general<1, 16>(B, N, M, F, C, K, Cout, act, nn_index, nn_count, bin_index, input, depthwise_filter,
+                                                     pointwise_weights, bias, scale, shift, output, st);
+        return r == 2 ? sc_launch_general<2, 32>(B, N, M, F, C, K, Cout, act, nn_index, nn_count, bin_index, input, depthwise_filter,
+                                                 pointwise_weights, bias, scale, shift, output, st)
+                      : sc_launch_general<1, 32>(B, N, M, F, C, K, Cout, act, nn_index, nn_count, bin_index, input, depthwise_filter,
+                                                 pointwise_weights, bias, scale, shift, output, st);
+    }
     if (C <= 64)
         return r == 2 ? sc_launch<2, 16>(B, N, M, F, C, K, Cout, act, nn_index, nn_count, bin_index, input, depthwise_filter,
                                          pointwise_weights, bias, scale, shift, output, st)

@@ -99,16 +99,18 @@ class GraphPlan:
     On CPU tensors (oracle-backed tests) everything is built lazily on the spot."""
 
     def __init__(self, points, config, overlap=True, points_ready=None, decoder=True, global_kernel=None, global_radius=100.0,
-                 global_query=None, prepare_input=True):
+                 global_query=None, prepare_input=True, need_backward=None):
         """decoder=False: an encoder-only plan (the classification net); global_kernel: also the global graph of
         models/SPH3D_modelnet.py:83-93 (query = centroid of the last level's points, every remaining point a neighbour) with
         the bins of that kernel (global_query: the query points [B, 1, 3], default the centroid of the last level);
+        need_backward (default: torch.is_grad_enabled()): also build the transposed graphs the gradients gather over;
         prepare_input=False: `points` are coordinates only (no S3DIS input features to prepare).
         points_ready: optional event after which `points` is valid.  With it the two side streams wait only for the
         INPUT, not for everything queued on the main stream — so when the host runs ahead (it issues a step in about
         half the time the GPU needs), the sampling / graph construction of step t+1 overlaps the backward pass of step
         t instead of idling the main stream at every step boundary (measured: 5.8 ms of main-stream idle per step)."""
         self.config = config
+        self.need_backward = torch.is_grad_enabled() if need_backward is None else bool(need_backward)
         self.decoder = bool(decoder)
         self.global_kernel, self.global_radius, self.global_query = global_kernel, float(global_radius), global_query
         self._glob, self._glob_ev = None, None
@@ -207,13 +209,17 @@ class GraphPlan:
         c = self.config
         xyz = self.xyz_layers[l]
         # util.py:29 + models/SPH3D_s3dis.py:57: neighbour graph and bins of one point set, one fused kernel on the GPU
-        idx, cnt, dst, filt = s3g_util.build_intra_graph(xyz, c.radius[l], c.nn_uplimit[l], c.kernel)
+        idx, cnt, dst, filt = s3g_util.build_intra_graph(xyz, c.radius[l], c.nn_uplimit[l], c.kernel, **self._bw_kw())
         return dict(intra_idx=idx, intra_cnt=cnt, filt_idx=filt)
+
+    def _bw_kw(self):
+        # (positional compatibility with the oracle-backed stand-ins of the CPU tests: the keyword only when it is not the default)
+        return {} if self.need_backward else {"with_transpose": False}
 
     def _make_pool(self, l, g):
         g["inter_idx"] = s3g_util.gather_nd(g["intra_idx"], self.indices[l])       # models/SPH3D_s3dis.py:68-72
         g["inter_cnt"] = s3g_util.gather_nd(g["intra_cnt"], self.indices[l])
-        if self.config.pool_method == 'max' and g["inter_idx"].is_cuda:
+        if self.config.pool_method == 'max' and g["inter_idx"].is_cuda and self.need_backward:
             # the max-pool gradient gathers over the transposed pooling graph when one exists (tf_pool3d): built here, off the
             # critical path, like the transposes of the convolution graphs
             from .. import _tgraph
@@ -226,9 +232,9 @@ class GraphPlan:
         radius, uplimit = c.radius[L - 1 - l], c.nn_uplimit[L - 1 - l]
         xyz_c, xyz_unpool = self.xyz_layers[L - l], self.xyz_layers[L - 1 - l]     # = reversed(xyz_layers)[l], [l + 1]
         # build_graph_deconv (util.py:52-58) + spherical_kernel: the intra half fused, the inter search as is
-        intra_idx, intra_cnt, intra_dst, filt_idx = s3g_util.build_intra_graph(xyz_c, radius, uplimit, c.kernel)
+        intra_idx, intra_cnt, intra_dst, filt_idx = s3g_util.build_intra_graph(xyz_c, radius, uplimit, c.kernel, **self._bw_kw())
         from .. import tf_nnquery
-        if (xyz_c.is_cuda and c.unpool_method == 'mean' and s3g_util.neighbor_fn is s3g_util.build_sphere_neighbor
+        if (self.need_backward and xyz_c.is_cuda and c.unpool_method == 'mean' and s3g_util.neighbor_fn is s3g_util.build_sphere_neighbor
                 and tf_nnquery.get_radius_mode() == "compat"):
             # the search also counts the in-edges: first pass of the transposed graph of the un-pooling gradient
             inter_idx, inter_cnt, inter_dst = tf_nnquery.build_sphere_neighbor_counted(xyz_c, xyz_unpool, radius, uplimit)
@@ -239,6 +245,8 @@ class GraphPlan:
 
     def _pretranspose(self, g, n_src_conv, n_src_unpool=None):
         """build the transposed graphs the backward pass will ask for (cached in _tgraph), off the critical path"""
+        if not self.need_backward:
+            return
         from .. import _tgraph
         _tgraph.transpose(g["intra_idx"], g["intra_cnt"], n_src_conv, bin_index=g["filt_idx"],
                           num_bins=self.config.binSize)

@@ -183,14 +183,15 @@ def build_graph_deconv(xyz, xyz_unpool, radius, nn_uplimit):
     return intra_idx, intra_cnt, intra_dst, inter_idx, inter_cnt, inter_dst
 
 
-def build_intra_graph(xyz, radius, nn_uplimit, kernel):
+def build_intra_graph(xyz, radius, nn_uplimit, kernel, with_transpose=True):
     """Intra-level graph + spherical-kernel bins of one point set: what the model graphs obtain from
     ``neighbor_fn(xyz, xyz, ...)`` followed by ``spherical_kernel(xyz, xyz, ...)`` (models/SPH3D_s3dis.py:56-62), from ONE
     fused kernel on the HIP device (tf_nnquery.build_sphere_graph); on other tensors (the CPU-oracle-backed tests) the two
     calls are made one after the other.  -> nn_idx, nn_cnt, nn_dst, filt_idx"""
     from . import tf_nnquery
     if xyz.is_cuda and neighbor_fn is build_sphere_neighbor and tf_nnquery.get_radius_mode() == "compat":
-        return tf_nnquery.build_sphere_graph(xyz, radius, nn_uplimit, kernel)
+        # (with_transpose: also the counting pass of the transposed graph the convolution GRADIENTS gather over)
+        return tf_nnquery.build_sphere_graph(xyz, radius, nn_uplimit, kernel, with_transpose=with_transpose)
     idx, cnt, dst = neighbor_fn(xyz, xyz, radius=radius, nnsample=nn_uplimit)
     return idx, cnt, dst, spherical_kernel(xyz, xyz, idx, cnt, dst, radius, kernel=kernel)
 
@@ -282,6 +283,17 @@ def separable_conv3d(inputs,
     # inputs may be a PAIR (a, b): the layer of the reference applied to tf.concat((a, b), axis=2) — same variables, same result —
     # with the depthwise kernels reading the two tensors in place (tf_conv3d.depthwise_conv3d_concat)
     pair = inputs if isinstance(inputs, (tuple, list)) else None
+    infer_fused = (FUSE_SEPARABLE_INFERENCE and is_training is not None and not bool(is_training) and not torch.is_grad_enabled()
+                   and (activation_fn is elu or activation_fn is None))
+    if pair is not None and infer_fused and pair[0].is_cuda and getattr(tf_conv3d, "separable_fused_supported_dims", None) is not None \
+            and tf_conv3d.separable_fused_supported_dims(pair[0].shape[1], kernel_size, pair[0].shape[-1] + pair[1].shape[-1],
+                                                         depth_multiplier, nn_index.shape[2], num_out_channels) \
+            and (FUSE_SEPARABLE_INFERENCE is True
+                 or _fused_rows_pay(nn_index.shape[0] * nn_index.shape[1], pair[0].shape[-1] + pair[1].shape[-1], depth_multiplier,
+                                    num_out_channels)):
+        # inference: the one-kernel layer reads ONE input tensor; concatenating the pair (a copy of the layer's input) costs far
+        # less than the depthwise tensor the fused kernel never writes
+        inputs, pair = torch.cat(tuple(pair), dim=2), None
     if pair is not None:
         supported = getattr(tf_conv3d, "concat_supported", None)       # (the oracle-backed CPU stand-ins of the tests have none)
         if not (FUSE_CONV_CONCAT and pair[0].is_cuda and supported is not None and supported(pair[0], pair[1], torch.empty(
@@ -300,9 +312,8 @@ def separable_conv3d(inputs,
                                              use_xavier=use_xavier, stddev=stddev, with_decay=weight_decay)
         return _gemm_tail(outputs.reshape(-1, num_in_channels), kernel, (batch_size, -1, num_out_channels), num_out_channels, scope,
                           activation_fn, with_bn, with_bias, reuse, is_training)
-    if (FUSE_SEPARABLE_INFERENCE and is_training is not None and not bool(is_training) and not torch.is_grad_enabled()
-            and (activation_fn is elu or activation_fn is None)
-            and tf_conv3d.separable_fused_supported(inputs, depthwise_kernel, nn_index, num_out_channels)):
+    if (infer_fused and tf_conv3d.separable_fused_supported(inputs, depthwise_kernel, nn_index, num_out_channels)
+            and (FUSE_SEPARABLE_INFERENCE is True or _fused_layer_pays(inputs, depth_multiplier, nn_index, num_out_channels))):
         # inference: the whole layer in one kernel, the depthwise tensor never written (csrc/sepconv.hip)
         store = get_variable_store()
         kernel = _variable_with_weight_decay(scope + '/weights', shape=[num_in_channels * depth_multiplier, num_out_channels],
@@ -423,7 +434,21 @@ FUSE_GEMM_BN = True    # the statistics of that tail from the GEMM's epilogue wh
 FUSE_POOL_SKIP = True             # pool3d_with_skip: the skip connection's gradient is added inside the max-pool gradient kernel
 FUSE_CONV_CONCAT = True           # separable_conv3d((a, b), ...): depthwise kernels over two inputs in place (tf_conv3d.depthwise_conv3d_concat)
 FUSE_LOGITS_CONCAT = True         # pointwise_conv3d_concat: few-output layer over two operand halves (tf_gemm.linear_concat2)
-FUSE_SEPARABLE_INFERENCE = True   # is_training=False under torch.no_grad(): separable_conv3d as ONE kernel (tf_conv3d.separable_conv3d_fused)
+# is_training=False under torch.no_grad(): separable_conv3d as ONE kernel (tf_conv3d.separable_conv3d_fused).
+#   "auto" (default): where the one-kernel layer is the faster one (measured, tools/exp_sepconv_layers.py: with the pointwise
+#                     weights resident in registers always; with W streamed per tile — wider layers — from 16 384 output points up:
+#                     at 6144 x 1024 -> 512 the per-tile W reads cost more than the depthwise tensor's round trip saves);
+#   True: wherever the kernel covers the shape;  False: never.
+FUSE_SEPARABLE_INFERENCE = "auto"
+
+
+def _fused_rows_pay(rows, C, r, Cout):
+    small = C <= 128 and C * r <= 256 and Cout <= 128          # sepconv_fused_kernel: W in registers
+    return small or rows >= 16384
+
+
+def _fused_layer_pays(inputs, depth_multiplier, nn_index, num_out_channels):
+    return _fused_rows_pay(nn_index.shape[0] * nn_index.shape[1], inputs.shape[-1], depth_multiplier, num_out_channels)
 FUSE_ELU_BN = True     # fused sph3d::elu_bn for the ELU -> BN tail (same variables / moving statistics as the unfused ops)
 
 

@@ -157,8 +157,14 @@ def depthwise_conv3d_grad(input, filter, grad_output, nn_index, nn_count, bin_in
 
 
 # ---- the whole separable layer in one kernel, inference only (csrc/sepconv.hip) ---------------------------
+def separable_fused_supported_dims(N, F, C, r, K, Cout):
+    """shapes sph3d_separable_conv3d_fused covers, by dimensions"""
+    return bool(_lib.lib().sph3d_separable_conv3d_fused_supported(int(N), int(F), int(C), int(r), int(K), int(Cout)))
+
+
 def separable_fused_supported(input, filter, nn_index, num_out_channels):
-    """shapes sph3d_separable_conv3d_fused covers (C <= 128, C*r <= 256, Cout <= 128 in multiples of 16)"""
+    """shapes sph3d_separable_conv3d_fused covers: r in {1, 2}, C % 4 == 0 and C <= 128 or a multiple of 128, Cout <= 512 in
+    multiples of 16 (every separable layer of the S3DIS / ShapeNet plans)"""
     if not (input.is_cuda and input.dim() == 3 and filter.dim() == 3 and nn_index.dim() == 3):
         return False
     return bool(_lib.lib().sph3d_separable_conv3d_fused_supported(input.shape[1], filter.shape[0], input.shape[2],

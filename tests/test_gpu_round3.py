@@ -395,6 +395,14 @@ SEPCONV_CASES = [
     ("uniform", 2, 500, 500, 0.15, 24, [4, 2, 1], 36, 2, 16),       # C*r = 72: k padded to 80; 9 bins; one column block
     ("modelnet", 1, 1500, 1500, 0.1, 48, [8, 2, 3], 8, 1, 32),      # 49 bins, narrow input
     ("uniform", 9, 257, 257, 0.2, 64, [8, 2, 2], 32, 2, 96),
+    # the general kernel (round 4): accumulators resident, W streamed per 128-channel k slice
+    ("s3dis", 2, 2048, 2048, 0.2, 64, [8, 2, 2], 128, 2, 256),      # S3DIS level 1, first layer: one slice, 16 column blocks
+    ("s3dis", 2, 2048, 2048, 0.2, 64, [8, 2, 2], 256, 2, 256),      # level 1, second layer: two slices
+    ("s3dis", 16, 384, 384, 0.8, 64, [8, 2, 2], 512, 2, 512),       # level 3: four slices, 32 column blocks, 16-point tiles
+    ("uniform", 2, 300, 128, 0.4, 64, [8, 2, 2], 1024, 2, 512),     # the decoder's widest layer: eight slices
+    ("uniform", 3, 700, 333, 0.15, 32, [8, 2, 2], 64, 2, 256),      # narrow input, wide output (LPE 16), ragged last tile
+    ("uniform", 2, 500, 500, 0.15, 24, [4, 2, 1], 96, 1, 144),      # partial slice (96 of 128 channels), r = 1, 9 column blocks
+    ("modelnet", 1, 1500, 1500, 0.1, 48, [8, 2, 3], 256, 1, 64),    # r = 1, two slices, 49 bins
 ]
 
 
@@ -445,10 +453,35 @@ def test_fused_inference_separable_conv_rejects_uncovered_shapes(dev):
     x, dw = torch.randn(1, 64, 256, device=dev), torch.randn(33, 256, 2, device=dev)
     idx = torch.zeros(1, 64, 8, dtype=torch.int32, device=dev)
     cnt = torch.ones(1, 64, dtype=torch.int32, device=dev)
-    assert not tf_conv3d.separable_fused_supported(x, dw, idx, 128)          # C = 256
-    assert not tf_conv3d.separable_fused_supported(x[..., :64], dw[:, :64], idx, 200)
+    assert tf_conv3d.separable_fused_supported(x, dw, idx, 128)              # C = 256: the general kernel (round 4)
+    assert not tf_conv3d.separable_fused_supported(x[..., :64], dw[:, :64], idx, 200)        # Cout % 16 != 0
+    assert not tf_conv3d.separable_fused_supported(x[..., :192], dw[:, :192], idx, 128)       # C > 128 and not a multiple of 128
     with pytest.raises(RuntimeError, match="not covered"):
-        tf_conv3d.separable_conv3d_fused(x, dw, torch.randn(512, 128, device=dev), idx, cnt, idx)
+        tf_conv3d.separable_conv3d_fused(x[..., :192].contiguous(), dw[:, :192].contiguous(), torch.randn(384, 128, device=dev),
+                                         idx, cnt, idx)
+
+
+def test_fused_inference_layer_covers_every_separable_layer_of_the_plans():
+    """VERDICT r3 / SURVEY 8f.3: sc_shape_ok for all 16 separable layers of the S3DIS plan (8 encoder + 8 decoder, the decoder's
+    inputs being the concatenation [un-pooled | skip]) and of the ShapeNet plan (same channel plan)"""
+    cfg = s3dis_net.s3dis_config(8192)
+    layers = []
+    c_in, skips = cfg.mlp, []
+    pts = [cfg.num_input] + cfg.num_sample
+    for l in range(4):
+        for j, co in enumerate(cfg.channels[l]):
+            layers.append((pts[l], c_in, cfg.multiplier[l][j], co))
+            c_in = co
+        skips.append(c_in)
+    for l in range(4):                                     # decoder level l works on point set 3 - l ... (models/SPH3D_s3dis.py:85-110)
+        lev = 3 - l
+        c_cat = c_in + skips[lev]
+        for j, co in enumerate(cfg.channels[lev]):
+            layers.append((pts[lev], c_cat if j == 0 else cfg.channels[lev][0], cfg.multiplier[lev][j], co))
+        c_in = cfg.channels[lev][-1]
+    assert len(layers) == 16
+    for n, c, r, co in layers:
+        assert tf_conv3d.separable_fused_supported_dims(n, 33, c, r, 64, co), (n, c, r, co)
 
 
 @pytest.mark.parametrize("with_bn", [True, False])
