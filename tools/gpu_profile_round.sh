@@ -8,6 +8,9 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 timeout 900 python bench.py > $OUT/${TAG}_bench_default.log 2> $OUT/${TAG}_bench_default.err; echo "bench rc=$?"
+# secondary lines (BASELINE configs 2, 3, 5 and the inference forward): same contract, not the headline
+for c in modelnet shapenet scannet; do timeout 400 python bench.py --config $c --steps 20 --warmup 3 > $OUT/${TAG}_bench_$c.log 2> $OUT/${TAG}_bench_$c.err; done
+timeout 400 python bench.py --eval --steps 20 --warmup 3 > $OUT/${TAG}_bench_eval.log 2> $OUT/${TAG}_bench_eval.err
 cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_prof.log 2>&1; echo "prof rc=$?"
 cd $GRAFT_REPO_ROOT
 python - <<PY
@@ -29,13 +32,13 @@ if tr:
 PY
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $pass | cut -c1-3)
-  for cfg in "fwd:TILED=" "fwdt:TILED=1" "bwd:TILED="; do
+  for cfg in "fwd:LDS=" "fwdl:LDS=1" "bwd:LDS="; do
     name=${cfg%%:*}; env=${cfg#*:}; mode=fwd; [ "$name" = "bwd" ] && mode=bwd
     bash tools/gpu_pmc3.sh ${TAG}_${name}_$n tools/exp_conv_pmc.py "$env MODE=$mode C=128" "$pass" dwconv | tail -2
   done
 done
 # SQ counters: the conv gather / gradient (instruction mix, waits) and the GEMMs (MFMA pipe busy cycles)
-for cfg in "fwd:MODE=fwd" "bwd:MODE=bwd"; do
+for cfg in "fwd:MODE=fwd" "bwd:MODE=bwd" "fwdl:MODE=fwd LDS=1"; do
   name=${cfg%%:*}; env=${cfg#*:}
   bash tools/gpu_pmc3.sh ${TAG}_sq1_$name tools/exp_conv_pmc.py "$env C=128" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" dwconv | tail -2
   bash tools/gpu_pmc3.sh ${TAG}_sq2_$name tools/exp_conv_pmc.py "$env C=128" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" dwconv | tail -2

@@ -3,7 +3,7 @@ usage: python tools/update_pmc_traffic.py [tag]   (tag = r03)
 traffic bytes per launch = FETCH_SIZE[KB] * 2 * 1024 + WRITE_SIZE[KB] * 1024 (the x2 is the gfx950 FETCH_SIZE correction of
 MI355X_MICROARCH.md for 16-B-per-lane reads, which all of these kernels issue)."""
 import csv, json, os, sys
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles") + "/"
 
 
@@ -31,7 +31,7 @@ def traffic(tag, pat, extra=None):
 for key, tag, pat, extra in (
         ("sph3d_depthwise_conv3d[16, 8192, 8192, 33, 128, 2, 64]", "fwd", "dwconv_fwd_multi", None),
         ("sph3d_depthwise_conv3d_grad_t[16, 8192, 8192, 33, 128, 2]", "bwd", "dwconv_bwd_t_vec<2, 4, 17", None),
-        ("sph3d_depthwise_conv3d_tiled[16, 8192, 8192, 33, 128, 2]", "fwdt", "dwconv_tile_fwd_whole", None),
+        ("sph3d_depthwise_conv3d_lds[16, 8192, 8192, 33, 128, 2]", "fwdl", "dwconv_fwd_lds", None),
         ("sph3d_pointwise_gemm[131072, 256, 128, 0, 0]", "gemmnn", "gemm_f32_mfma", None),
         ("sph3d_pointwise_gemm_bnstats[131072, 256, 128]", "gemmnn", "gemm_f32_mfma", None),
         ("sph3d_pointwise_gemm_tn[32768, 1024, 128]", "gemmtn", "gemm_f32_mfma", "gemm_reduce_splits"),
