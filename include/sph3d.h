@@ -55,8 +55,16 @@ const char* sph3d_build_info(void);          /* "gfx950 hipcc <ver> ..." */
  * chain (:59): query (i,j) is searched with the radius left behind by the
  * previous query of reference-thread (i mod 32, j mod 1024).
  * Growth is bounded: after SPH3D_MAX_GROWTH_PASSES empty passes the query is
- * stored with nn_count = 0 (the reference would spin forever). */
+ * stored with nn_count = 0 (the reference would spin forever).
+ * Two kernels share the work (csrc/nngrid.hip, csrc/nnquery.hip): the early positions of every chain — radius <= 2 * radius,
+ * the queries that would otherwise scan the whole cloud for a handful of hits — are searched over a cell grid; the late
+ * ones, and the whole call whenever some query needs the reference's growth (device-side flag, no host round trip), by the
+ * chain walk over the cloud.  Same rows bit for bit either way.  The grid lives in a library-owned per-stream device buffer
+ * (hipMalloc on first use, kept; the reference signature has no workspace).  Environment SPH3D_NNGRID=0 (read once) turns
+ * the grid off. */
 #define SPH3D_MAX_GROWTH_PASSES 4096
+/* diagnostic: calls so far in this process whose early positions went through the cell grid */
+long long sph3d_nngrid_launches(void);
 int sph3d_build_sphere_neighbor(int B, int N, int M, int nn_sample, float radius,
                                 const float* database, const float* query,
                                 int* nn_index, int* nn_count, float* nn_dist,

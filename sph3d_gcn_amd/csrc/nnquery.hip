@@ -17,8 +17,10 @@
 //     bit patterns (6 rounds) and the inner loop is sub/mul/add/compare only: no sqrt per pair,
 //     bit-identical decisions.
 //   * -ffp-contract=off: d2 = (dx*dx + dy*dy) + dz*dz must round exactly like the oracle.
+#include <cstdlib>
 #include "common.hpp"
 #include "sphere_bin.hpp"
+#include "nnquery.hpp"
 
 namespace sph3d {
 
@@ -27,34 +29,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kWavesPerWG = 16;
 constexpr int kMaxChunk = 12288;   // points per LDS chunk (3 * 12288 * 4 B = 144 KB)
 constexpr int kThrTable = 64;      // positions of the radius sequence with a precomputed threshold
-
-// the reference's predicate on the euclidean distance s (tf_nnquery_gpu.cu:49)
-__device__ __forceinline__ bool in_range(float s, float r)
-{
-    return s < r && (double)fabsf(s - r) > 1e-6;
-}
-
-// Wave-cooperative, all 64 lanes active, r wave-uniform.
-// Returns the smallest non-negative float T with !in_range(sqrtf(T), r); then
-// in_range(sqrtf(d2), r) == (d2 < T) for every d2 >= 0 (and false for NaN on both sides).
-__device__ float range_threshold(float r)
-{
-    if (!in_range(0.0f, r)) return 0.0f;
-    const unsigned lane = (unsigned)lane_id();
-    unsigned lo = 0u;             // in_range holds at lo
-    unsigned hi = 0x7f800000u;    // +inf: in_range fails
-    while (hi - lo > 1u) {
-        const unsigned span = hi - lo;
-        const unsigned step = span / 65u + 1u;
-        const unsigned long long c = (unsigned long long)lo + (unsigned long long)step * (lane + 1u);
-        const bool p = (c < hi) && in_range(sqrtf(__uint_as_float((unsigned)c)), r);
-        const int nt = __popcll(__ballot(p));   // p is a prefix of the lanes (monotone predicate)
-        const unsigned long long nhi = (unsigned long long)lo + (unsigned long long)step * (unsigned)(nt + 1);
-        if (nhi < hi) hi = (unsigned)nhi;
-        lo = lo + step * (unsigned)nt;
-    }
-    return __uint_as_float(hi);
-}
 
 // LDS image of a cloud chunk: blocks of 128 points (one trip of the scan = two strips of 64), each block
 // x[strip 0][64] x[strip 1][64] y[0][64] y[1][64] z[0][64] z[1][64] (384 floats).  A lane's operands for the two strips of
@@ -88,18 +62,6 @@ __device__ __forceinline__ void stage_cloud(const float* __restrict__ dbi, int c
 extern "C" __device__ int sph3d_writelane_i32(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 __device__ __forceinline__ int write_lane(int old, int val, int lane) { return sph3d_writelane_i32(val, lane, old); }
 
-// exclusive prefix sum of v over the lanes of a wave (all lanes active)
-__device__ __forceinline__ int wave_excl_scan(int v)
-{
-    int incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int u = __shfl_up(incl, o);
-        if (lane_id() >= o) incl += u;
-    }
-    return incl - v;
-}
-
 // DEFER: the hits of a query are collected as bare indices in a per-chain LDS list during the scan, and the outputs of
 // the finished query (indices, sqrt(sqrt(d2)), zero fill) are produced by ONE coalesced pass over its <= K slots.  The
 // first version wrote nn_index / nn_dist from inside the strip loop: every strip with at least one hit ran two
@@ -108,22 +70,18 @@ __device__ __forceinline__ int wave_excl_scan(int v)
 // neighbour (the operands dx, dy, dz, sqrt-distance are in registers there) and, when a transposed graph will be
 // needed, counts the edge into its (source point, bin) segment — the atomic's return value is the edge's position in
 // the segment (graph.hip).  Replaces one launch + one pass over [B,M,K] for the bins and one for the segment counts.
-struct GraphFuse {
-    int n, p, q, F;          // spherical kernel sizes, F = n*p*q + 1
-    float radius;            // nominal radius of the binning (not the chain's grown radius)
-    int* filt;               // [B,M,K] bin ids
-    int* deg;                // [B*N*F] segment counters (zeroed by the caller) or nullptr
-    int* slotPos;            // [B*M*K]
-    int* binUsed;            // [F]
-    int ocml;                // 1: the device library's atan2f (the reference as it builds here), 0: the shared correctly rounded one
-};
 
 template <int CPW, bool MULTI, bool DEFER, bool FUSE>
 __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
     int B, int N, int M, int K, float radius0, int chunkN, int groups, int fixed, GraphFuse fx,
     const float* __restrict__ database, const float* __restrict__ query,
-    int* __restrict__ nnIndex, int* __restrict__ nnCount, float* __restrict__ nnDist)
+    int* __restrict__ nnIndex, int* __restrict__ nnCount, float* __restrict__ nnDist, const int* __restrict__ gate, int gridDone)
 {
+    // gate != nullptr: the cell-grid search (nngrid.hip) ran in front and — unless it raised its flag — has produced the rows of
+    // the first `gridDone` queries of every chain (the chain positions whose radius is small): the chains start behind them, at
+    // the radius of that position.  With the flag raised this kernel computes the whole call.
+    const int kstart = (gate != nullptr && *gate == 0) ? gridDone : 0;
+    if ((long long)kstart * kRefBlock >= M) return;       // everything came from the grid
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int* lhits = reinterpret_cast<int*>(lds + 3 * ((chunkN + 127) & ~127));      // [wave][CPW][K] when DEFER
     // Every chain's radius walks the SAME sequence r_0 = radius0, r_{k+1} = float(double(r_k) + 0.05) (tf_nnquery_gpu.cu:59);
@@ -157,7 +115,11 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
     for (int c = 0; c < CPW; c++) {
         t[c] = (g * kWavesPerWG + wave) * CPW + c;
         r[c] = radius0;
-        kpos[c] = 0;
+        kpos[c] = kstart;
+    }
+    for (int k = 0; k < kstart; k++) {                      // kstart > 0 only without carries between clouds (B <= 32, not `fixed`)
+#pragma unroll
+        for (int c = 0; c < CPW; c++) r[c] = (float)((double)r[c] + 0.05);
     }
 
     auto threshold_of = [&](int c) -> float {
@@ -173,7 +135,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
         float qx[CPW], qy[CPW], qz[CPW], thr[CPW];
 #pragma unroll
         for (int c = 0; c < CPW; c++) {
-            j[c] = t[c];
+            j[c] = t[c] + kstart * kRefBlock;
             has[c] = (t[c] < nt) && (j[c] < M);
             s[c] = 0;
             passes[c] = 0;
@@ -454,6 +416,13 @@ __global__ __launch_bounds__(256) void nnquery_cube_kernel(
     }
 }
 
+// clears the fused counters again before the chain kernel recomputes a call the grid search gave up on
+__global__ void gated_zero_kernel(const int* __restrict__ gate, int* __restrict__ p, long long n)
+{
+    if (*gate == 0) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0;
+}
+
 // bytes of LDS for the deferred hit lists (0 = write hits from inside the scan: K too large for LDS lists)
 static size_t hits_bytes(int CPW, int K)
 {
@@ -465,7 +434,7 @@ template <int CPW, bool MULTI, bool DEFER>
 static int launch_sphere(int B, int N, int M, int K, float radius, int chunkN,
                          const float* database, const float* query,
                          int* nn_index, int* nn_count, float* nn_dist, hipStream_t stream, int fixed,
-                         const GraphFuse* fuse = nullptr)
+                         const GraphFuse* fuse = nullptr, const int* gate = nullptr, int grid_done = 0)
 {
     const int nb = B < kRefGrid ? B : kRefGrid;
     const int nt = M < kRefBlock ? M : kRefBlock;
@@ -480,7 +449,7 @@ static int launch_sphere(int B, int N, int M, int K, float radius, int chunkN,
                 if (rc) return rc;
             }
             hipLaunchKernelGGL(kernf, dim3(nb * groups), dim3(kWavesPerWG * 64), lds, stream,
-                               B, N, M, K, radius, chunkN, groups, fixed, *fuse, database, query, nn_index, nn_count, nn_dist);
+                               B, N, M, K, radius, chunkN, groups, fixed, *fuse, database, query, nn_index, nn_count, nn_dist, gate, grid_done);
             return check_launch("sph3d_build_sphere_graph");
         }
     }
@@ -491,7 +460,7 @@ static int launch_sphere(int B, int N, int M, int K, float radius, int chunkN,
         if (rc) return rc;
     }
     hipLaunchKernelGGL(kern, dim3(nb * groups), dim3(kWavesPerWG * 64), lds, stream,
-                       B, N, M, K, radius, chunkN, groups, fixed, GraphFuse{}, database, query, nn_index, nn_count, nn_dist);
+                       B, N, M, K, radius, chunkN, groups, fixed, GraphFuse{}, database, query, nn_index, nn_count, nn_dist, gate, grid_done);
     return check_launch("sph3d_build_sphere_neighbor");
 }
 
@@ -525,9 +494,24 @@ static int sphere_neighbor(int fixed, int B, int N, int M, int nn_sample, float 
         chunkN = maxChunk;
     }
     if (fused) *fused = (fuse != nullptr) && hb != 0;       // the bins come from the deferred output pass
+    if (hb == 0) fuse = nullptr;
+    // The cell-grid search first (nngrid.hip): complete unless some query has no neighbour inside the nominal radius — then
+    // (device flag `gate`) the chain kernel below recomputes the call, after the fused counters have been cleared again.
+    const int* gate = nullptr;
+    int grid_done = 0;
+    static const bool grid_on = !(getenv("SPH3D_NNGRID") && atoi(getenv("SPH3D_NNGRID")) == 0);
+    if (grid_on) {
+        const int g = nngrid_search(B, N, M, nn_sample, radius, fixed, database, query, nn_index, nn_count, nn_dist, fuse, st, &gate,
+                                    &grid_done);
+        if (g < 0) return g;
+        if (g > 0 && fuse != nullptr && fuse->deg != nullptr) {
+            const long long cnt = (long long)B * N * fuse->F + fuse->F;
+            hipLaunchKernelGGL(gated_zero_kernel, dim3(256), dim3(256), 0, st, gate, fuse->deg, cnt);
+        }
+    }
 #define SPH3D_NN(CP, MU)                                                                                          \
-    return hb ? launch_sphere<CP, MU, true>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st, fixed, fuse) \
-              : launch_sphere<CP, MU, false>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st, fixed)
+    return hb ? launch_sphere<CP, MU, true>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st, fixed, fuse, gate, grid_done) \
+              : launch_sphere<CP, MU, false>(B, N, M, nn_sample, radius, chunkN, database, query, nn_index, nn_count, nn_dist, st, fixed, nullptr, gate, grid_done)
     if (multi) { SPH3D_NN(1, true); }
     if (cpw == 4) { SPH3D_NN(4, false); }
     if (cpw == 2) { SPH3D_NN(2, false); }
