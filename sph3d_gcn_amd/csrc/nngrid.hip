@@ -32,16 +32,18 @@
 // grid build 19 + search of positions 0-2 75 + chain kernel for positions 3-7 300 = 412 us.  Level 1 (16 x 2048, r_0 = 0.2, two
 // positions, all from the grid): 84 -> 58 us.  Pooling graph 8192 -> 2048: 158 -> 131 us with the transposed graph's finish.
 #include <atomic>
+#include <cstdlib>
 #include "common.hpp"
 #include "sphere_bin.hpp"
 #include "nnquery.hpp"
 
 namespace sph3d {
 
-constexpr int kGridMaxCells = 32768;     // LDS histogram of the build kernel (128 KB)
+constexpr int kGridMaxCells = 8192;      // LDS histogram of the build kernels (32 KB: they must fit beside the step's other kernels)
 constexpr int kGridMinCells = 512;       // below this 27 cells are too large a share of the cloud
 constexpr int kGridMaxK = 256;           // sorted hit lists of a wave's four queries: 4 * K * 2 B
-constexpr int kGridMaxPos = 8;           // chain positions the grid may take (r_k <= 2 r_0 bounds it further)
+constexpr int kGridMaxPos = 8;           // chain positions the grid may take (r_k <= kGridReach * r_0 bounds it further)
+constexpr int kGridReach = 3;            // ... in units of r_0 = cells a query looks in every direction: (2 * 3 + 1)^2 = 49 columns
 
 struct GridHdr {
     float minx, miny, minz, invh;
@@ -111,9 +113,9 @@ __device__ __forceinline__ void sort_by_cell(int n, int ncell, int* hist, int* t
 
 // npos: chain positions the grid takes (queries j < npos * 1024; `fixed` mode: every query is position 0, npos = 1 and all M)
 __global__ __launch_bounds__(1024) void nngrid_build_kernel(
-    int N, int M, int npos, int fixed, float radius, const float* __restrict__ database, const float* __restrict__ query,
+    int N, int M, int npos, int fixed, float radius, const float* __restrict__ database,
     int* __restrict__ flag, GridRadii* __restrict__ radii, GridHdr* __restrict__ hdr, int* __restrict__ cellStart,
-    float4* __restrict__ pts, int* __restrict__ qorder)
+    float4* __restrict__ pts)
 {
     extern __shared__ int hist[];                 // [kGridMaxCells]
     __shared__ float redf[6][16];
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(1024) void nngrid_build_kernel(
         // cell size: two points closer than r_0 must sit in the same or in adjacent cells (a query of radius r looks
         // ceil(r / h) cells far).  h = 1.001 * r_0 leaves a margin of 1e-3 cells, three orders of magnitude above the rounding
         // of (v - lo) * invh for grids of this size
-        const int maxCells = kGridMaxCells / npos;        // the queries' histogram has one copy of the grid per position
+        const int maxCells = kGridMaxCells;
         float h = radius * 1.001f;
         int n3[3] = {0, 0, 0};
         bool ok = !bad && h > 0.0f && h < INFINITY;
@@ -199,12 +201,31 @@ __global__ __launch_bounds__(1024) void nngrid_build_kernel(
                  [&](int i, int pos) {
                      P[pos] = make_float4(db[(size_t)i * 3], db[(size_t)i * 3 + 1], db[(size_t)i * 3 + 2], __int_as_float(i));
                  });
-    // the queries the grid takes, by (position, cell): query j sits at position j / 1024 of its chain
-    const float* q = query + (size_t)b * M * 3;
-    int* qo = qorder + (size_t)b * M;
-    sort_by_cell(H.nq, ncell * npos, hist, tmp, nullptr,
-                 [&](int j) { return (fixed ? 0 : j / kRefBlock) * ncell + cell3(q + (size_t)j * 3); },
-                 [&](int j, int pos) { qo[pos] = j; });
+}
+
+// The visiting order of the queries the grid takes: by (position, cell) — query j sits at position j / 1024 of its chain, and a
+// wave's four queries should share radius and cells.  One workgroup per (cloud, position) sorts that position's <= 1024
+// queries by cell (`fixed` mode: consecutive slices of 1024 queries, all at the nominal radius).
+__global__ __launch_bounds__(1024) void nngrid_qorder_kernel(int M, int nslices, const float* __restrict__ query,
+                                                             const GridHdr* __restrict__ hdr, int* __restrict__ qorder)
+{
+    extern __shared__ int hist[];                 // [kGridMaxCells]
+    __shared__ int tmp[16];
+    const int b = (int)blockIdx.x / nslices, k = (int)blockIdx.x % nslices;
+    const GridHdr H = hdr[b];
+    const int j0 = k * kRefBlock;
+    if (H.nx == 0 || j0 >= H.nq) return;
+    const int n = H.nq - j0 < kRefBlock ? H.nq - j0 : kRefBlock;
+    const int nx = H.nx, ny = H.ny, nz = H.nz;
+    const float mx = H.minx, my = H.miny, mz = H.minz, invh = H.invh;
+    const float* q = query + ((size_t)b * M + j0) * 3;
+    int* qo = qorder + (size_t)b * M + j0;
+    sort_by_cell(n, nx * ny * nz, hist, tmp, nullptr,
+                 [&](int j) {
+                     const float* p = q + (size_t)j * 3;
+                     return (cell_of(p[0], mx, invh, nx) * ny + cell_of(p[1], my, invh, ny)) * nz + cell_of(p[2], mz, invh, nz);
+                 },
+                 [&](int j, int pos) { qo[pos] = j0 + j; });
 }
 
 // exclusive prefix sum over the 16 lanes of a quarter wave (all lanes active)
@@ -238,10 +259,10 @@ __global__ __launch_bounds__(64) void nngrid_search_kernel(
     const GridHdr H = hdr[b];
     if (H.nx == 0 || part * 4 >= H.nq) return;         // uniform per workgroup
     const int lane = lane_id(), g = lane >> 4, l16 = lane & 15;
-    // LDS: bitmaps u32 [4][W]; column bounds int2 [4][32]; sorted hits u16 [4][K]
+    // LDS: bitmaps u32 [4][W]; column bounds int2 [4][64]; sorted hits u16 [4][K]
     unsigned* bm = reinterpret_cast<unsigned*>(smem) + (size_t)g * W;
-    int2* bounds = reinterpret_cast<int2*>(smem + (size_t)4 * W * 4) + g * 32;
-    unsigned short* list = reinterpret_cast<unsigned short*>(smem + (size_t)4 * W * 4 + 4 * 32 * 8) + (size_t)g * K;
+    int2* bounds = reinterpret_cast<int2*>(smem + (size_t)4 * W * 4) + g * 64;
+    unsigned short* list = reinterpret_cast<unsigned short*>(smem + (size_t)4 * W * 4 + 4 * 64 * 8) + (size_t)g * K;
 
     const int qpos = part * 4 + g;                         // the quarter's position in the visiting order
     const bool valid = qpos < H.nq;
@@ -260,9 +281,9 @@ __global__ __launch_bounds__(64) void nngrid_search_kernel(
     const int cx = cell_of(qx, H.minx, H.invh, nx), cy = cell_of(qy, H.miny, H.invh, ny), cz = cell_of(qz, H.minz, H.invh, nz);
     const float T = radii->thr[kq];
     // cells to look at in every direction: ceil(r / h), one more than the floor to be on the safe side of the rounding
-    // (r_k <= 2 r_0 < 2 h: at most 2)
+    // (r_k <= 3 r_0 < 3 h: at most 3)
     int c = (int)(radii->rk[kq] * H.invh) + 1;
-    c = c > 2 ? 2 : c;
+    c = c > kGridReach ? kGridReach : c;
     const int side = 2 * c + 1;
     const int ncols = valid ? side * side : 0;
     const int zlo = cz - c > 0 ? cz - c : 0, zhi = cz + c < nz - 1 ? cz + c : nz - 1;
@@ -378,7 +399,7 @@ int nngrid_search(int B, int N, int M, int K, float radius, int fixed, const flo
         float rk = radius;
         while (npos < kGridMaxPos) {
             rk = (float)((double)rk + 0.05);
-            if (!(rk <= 2.0f * radius)) break;
+            if (!(rk <= kGridReach * radius)) break;
             npos++;
         }
         const int have = (M + kRefBlock - 1) / kRefBlock;
@@ -401,19 +422,14 @@ int nngrid_search(int B, int N, int M, int K, float radius, int fixed, const flo
     int rc = check_hip(hipMemsetAsync(flag, 0, 16, st), "nngrid: memset");
     if (rc) return rc;
     const size_t ldsBuild = sizeof(int) * (size_t)kGridMaxCells;
-    static bool attr_done = false;
-    if (!attr_done) {
-        rc = check_hip(hipFuncSetAttribute((const void*)nngrid_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBuild),
-                       "nngrid: hipFuncSetAttribute");
-        if (rc) return rc;
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(nngrid_build_kernel, dim3(B), dim3(1024), ldsBuild, st, N, M, npos, fixed, radius, database, query, flag,
-                       radii, hdr, cellStart, pts, qorder);
+    hipLaunchKernelGGL(nngrid_build_kernel, dim3(B), dim3(1024), ldsBuild, st, N, M, npos, fixed, radius, database, flag,
+                       radii, hdr, cellStart, pts);
     const int nq = fixed ? M : (M < npos * kRefBlock ? M : npos * kRefBlock);
+    const int nslices = (nq + kRefBlock - 1) / kRefBlock;
+    hipLaunchKernelGGL(nngrid_qorder_kernel, dim3(B * nslices), dim3(1024), ldsBuild, st, M, nslices, query, hdr, qorder);
     const int parts = (nq + 3) / 4;
     const int W = ((N + 31) / 32 + 15) & ~15;
-    const size_t lds = (size_t)4 * W * 4 + 4 * 32 * 8 + (size_t)4 * K * 2;
+    const size_t lds = (size_t)4 * W * 4 + 4 * 64 * 8 + (size_t)4 * K * 2;
     GraphFuse fx{};
     if (fuse != nullptr) fx = *fuse;
 #define SPH3D_GRID(FU)                                                                                                      \
