@@ -56,10 +56,11 @@ const char* sph3d_build_info(void);          /* "gfx950 hipcc <ver> ..." */
  * previous query of reference-thread (i mod 32, j mod 1024).
  * Growth is bounded: after SPH3D_MAX_GROWTH_PASSES empty passes the query is
  * stored with nn_count = 0 (the reference would spin forever).
- * Two kernels share the work (csrc/nngrid.hip, csrc/nnquery.hip): the early positions of every chain — radius <= 2 * radius,
- * the queries that would otherwise scan the whole cloud for a handful of hits — are searched over a cell grid; the late
- * ones, and the whole call whenever some query needs the reference's growth (device-side flag, no host round trip), by the
- * chain walk over the cloud.  Same rows bit for bit either way.  The grid lives in a library-owned per-stream device buffer
+ * When no query of a call needs that growth, the radius of a query is a function of its position in the chain alone, and
+ * every query is independent (csrc/nngrid.hip): the early positions — radius <= 3 * radius, the queries that would otherwise
+ * scan the whole cloud for a handful of hits — are searched over a cell grid, the late ones by an early-stopping scan per
+ * query.  Whenever some query does need the growth (device-side flag, no host round trip) the chain walk over the cloud
+ * (csrc/nnquery.hip) computes the call.  Same rows bit for bit either way.  The grid lives in a library-owned per-stream device buffer
  * (hipMalloc on first use, kept; the reference signature has no workspace).  Environment SPH3D_NNGRID=0 (read once) turns
  * the grid off. */
 #define SPH3D_MAX_GROWTH_PASSES 4096

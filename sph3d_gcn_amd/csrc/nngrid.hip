@@ -20,17 +20,21 @@
 //                         reference's scan order: its first nn_sample set bits are the row; distance, spherical-kernel bin
 //                         and the transposed graph's segment count are produced from them as in the chain kernel.
 //
-// Later positions stay with the chain kernel: their neighbourhoods hold hundreds of points, and the ascending scan with its
-// early stop is the cheaper way to the 64 smallest indices (measured: c = 3 costs as much as the chain's partial scan).
+// Later positions (nndense_kernel): their spheres hold hundreds of points, so the reference's ascending scan meets nn_sample
+// hits after a fraction of the cloud — a wave per query walks the cloud in index order, 256 points per trip, and stops there
+// (measured: a grid reach of 4-5 r_0 costs as much as that partial scan).  With the position's radius tabulated, those queries
+// are independent too: tens of thousands of waves where the chain kernel walks 1024 chains per cloud one query after the other.
 //
 // The rows are the chain kernel's, bit for bit, unless some query has no neighbour inside its radius (the reference then grows
-// the radius, for this query and for the rest of its chain): the search raises a device flag, and the chain kernel — which
-// runs behind it for the late positions anyway — starts from position 0 instead.  The same flag is raised for clouds the
-// grid cannot help (fewer than 512 cells: radius comparable to the extent) or cannot index (non-finite coordinates).
+// the radius, for this query and for the rest of its chain): the kernels raise a device flag, and the chain kernel — launched
+// behind them, returning at once otherwise — computes the call from position 0.  The same flag is raised for clouds the grid
+// cannot help (fewer than 512 cells: radius comparable to the extent) or cannot index (non-finite coordinates).
 //
-// Measured (MI355X, S3DIS level 0, 16 x 8192 points, r_0 = 0.1, K = 64; tools/exp_nngrid.py): chain kernel alone 472 us;
-// grid build 19 + search of positions 0-2 75 + chain kernel for positions 3-7 300 = 412 us.  Level 1 (16 x 2048, r_0 = 0.2, two
-// positions, all from the grid): 84 -> 58 us.  Pooling graph 8192 -> 2048: 158 -> 131 us with the transposed graph's finish.
+// Measured (MI355X, S3DIS level 0, 16 x 8192 points, r_0 = 0.1, K = 64, fused with bins and segment counts;
+// tools/exp_nngrid.py): chain kernel alone 472 us; grid build 16 + query order + search of positions 0-4 147 + dense scan of
+// positions 5-7 165 = 342 us (both kernels VALU-bound: ~3400 and ~1600 wave instructions per wave).  Level 1 (16 x 2048, two
+// positions, all from the grid): 84 -> 60 us.  In the training step (graph stream, beside the feature kernels) the fused graph
+// construction drops from 1.69 to 1.23 ms per step: 1767 -> 1788 blocks/s.
 #include <atomic>
 #include <cstdlib>
 #include "common.hpp"
@@ -49,8 +53,9 @@ struct GridHdr {
     float minx, miny, minz, invh;
     int nx, ny, nz, nq;                  // nx == 0: cloud not indexed (the flag is raised); nq: queries in the visiting order
 };
+constexpr int kMaxPositions = 64;        // positions of a chain at M <= 65536 queries
 struct GridRadii {
-    float thr[kGridMaxPos], rk[kGridMaxPos];
+    float thr[kMaxPositions], rk[kMaxPositions];      // exact threshold T(r_k) and radius of chain position k
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -149,11 +154,14 @@ __global__ __launch_bounds__(1024) void nngrid_build_kernel(
     if (nonfinite) bad = 1;
     __syncthreads();
     // the radius of position k and the exact threshold of its predicate: wave k computes T(r_k) (wave-cooperative search)
-    if (b == 0 && w < npos) {
-        float rk = radius;
-        for (int k = 0; k < w; k++) rk = (float)((double)rk + 0.05);      // tf_nnquery_gpu.cu:59, the chain kernel's sequence
-        const float T = range_threshold(rk);
-        if (lane == 0) { radii->thr[w] = T; radii->rk[w] = rk; }
+    if (b == 0) {
+        const int have = fixed ? 1 : (M + kRefBlock - 1) / kRefBlock;     // positions in use (<= kMaxPositions)
+        for (int k0 = w; k0 < have; k0 += 16) {
+            float rk = radius;
+            for (int k = 0; k < k0; k++) rk = (float)((double)rk + 0.05);  // tf_nnquery_gpu.cu:59, the chain kernel's sequence
+            const float T = range_threshold(rk);
+            if (lane == 0) { radii->thr[k0] = T; radii->rk[k0] = rk; }
+        }
     }
     if (tid == 0) {
         float l3[3], h3[3];
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(64) void nngrid_search_kernel(
         bounds[ci] = be;
     }
     __syncthreads();
-    // ---- scan: 32 candidates of the current run per trip (two loads per lane in flight) ----
+    // ---- scan: the runs of the columns, one after the other ----
     int col = 0, p = 0, e = 0;
     if (ncols > 0) { const int2 be = bounds[0]; p = be.x; e = be.y; }
     for (;;) {
@@ -311,24 +319,22 @@ __global__ __launch_bounds__(64) void nngrid_search_kernel(
             p = be.x; e = be.y;
         }
         if (__builtin_amdgcn_ballot_w64(p < e) == 0ull) break;
-        const int i0 = p + l16, i1 = p + 16 + l16;
-        const bool in0 = i0 < e, in1 = i1 < e;
-        const float4 c0 = P[in0 ? i0 : 0];
-        const float4 c1 = P[in1 ? i1 : 0];
-        p += 32;
-        {
-            const float dx = c0.x - qx, dy = c0.y - qy, dz = c0.z - qz;
-            const float d2 = (dx * dx + dy * dy) + dz * dz;        // tf_nnquery_gpu.cu:45-46
-            if (in0 && d2 < T) {
-                const unsigned id = (unsigned)__float_as_int(c0.w);
-                atomicOr(&bm[id >> 5], 1u << (id & 31u));
-            }
+        // 64 candidates of the run per trip: four 256-B loads per quarter in flight
+        float4 cd[4];
+        bool in[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = p + u * 16 + l16;
+            in[u] = i < e;
+            cd[u] = P[in[u] ? i : 0];
         }
-        {
-            const float dx = c1.x - qx, dy = c1.y - qy, dz = c1.z - qz;
-            const float d2 = (dx * dx + dy * dy) + dz * dz;
-            if (in1 && d2 < T) {
-                const unsigned id = (unsigned)__float_as_int(c1.w);
+        p += 64;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float dx = cd[u].x - qx, dy = cd[u].y - qy, dz = cd[u].z - qz;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;        // tf_nnquery_gpu.cu:45-46
+            if (in[u] && d2 < T) {
+                const unsigned id = (unsigned)__float_as_int(cd[u].w);
                 atomicOr(&bm[id >> 5], 1u << (id & 31u));
             }
         }
@@ -383,6 +389,104 @@ __global__ __launch_bounds__(64) void nngrid_search_kernel(
     }
 }
 
+// The positions beyond the grid's reach: their spheres hold hundreds of points, so the reference's ascending scan meets
+// nn_sample hits after a fraction of the cloud — a WAVE per query walks the cloud 128 points per trip in index order and stops
+// there.  No chain state (the radius of position k is tabulated), every query independent: 49 152 waves at S3DIS level 0
+// where the chain kernel walks 1024 chains per cloud one query after the other.  K <= 256 slots in LDS per wave.
+template <bool FUSE>
+__global__ __launch_bounds__(256) void nndense_kernel(
+    int B, int N, int M, int K, int j0, int parts, GraphFuse fx, int* __restrict__ flag, const GridRadii* __restrict__ radii,
+    const GridHdr* __restrict__ hdr, const float* __restrict__ database, const float* __restrict__ query,
+    int* __restrict__ nnIndex, int* __restrict__ nnCount, float* __restrict__ nnDist)
+{
+    extern __shared__ int lhits[];                    // [4][K]
+    int b, part;
+    xcd_decode((int)blockIdx.x, B, parts, b, part);
+    if (b < 0 || hdr[b].nx == 0) return;              // (a cloud the grid gave up on: the chain kernel recomputes the call)
+    const int lane = lane_id(), w = uniform((int)threadIdx.x >> 6);
+    const int j = j0 + part * 4 + w;
+    if (j >= M) return;
+    int* h = lhits + w * K;
+    const float* db = database + (size_t)b * N * 3;
+    const size_t row = (size_t)b * M + j;
+    const float qx = query[row * 3], qy = query[row * 3 + 1], qz = query[row * 3 + 2];
+    const float T = radii->thr[j / kRefBlock];
+    int s = 0;
+    // four strips of 64 points per trip, and the next trip's twelve loads are issued before this trip's points are tested:
+    // the walk is a chain of L2 round trips otherwise (one trip in flight: 164 us for S3DIS level 0's three late positions)
+    constexpr int S = 4;
+    float px[S], py[S], pz[S];
+    auto fetch = [&](int base, float* x, float* y, float* z) {
+#pragma unroll
+        for (int u = 0; u < S; u++) {
+            const int i = base + u * 64 + lane;
+            const int c = i < N ? i : N - 1;                    // points past the end: clamped here, masked at the test
+            x[u] = db[(size_t)c * 3]; y[u] = db[(size_t)c * 3 + 1]; z[u] = db[(size_t)c * 3 + 2];
+        }
+    };
+    fetch(0, px, py, pz);
+    for (int base = 0; base < N && s < K; base += 64 * S) {
+        float nx[S], ny[S], nz[S];
+        const bool more = base + 64 * S < N;
+        if (more) fetch(base + 64 * S, nx, ny, nz);
+        unsigned long long m[S];
+        bool hit[S];
+        unsigned long long any = 0ull;
+#pragma unroll
+        for (int u = 0; u < S; u++) {
+            const float dx = px[u] - qx, dy = py[u] - qy, dz = pz[u] - qz;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;        // tf_nnquery_gpu.cu:45-46
+            hit[u] = base + u * 64 + lane < N && d2 < T;
+            m[u] = __builtin_amdgcn_ballot_w64(hit[u]);
+            any |= m[u];
+        }
+        if (any != 0ull) {
+            // ascending index: a strip's hits take their slots before the next strip's
+#pragma unroll
+            for (int u = 0; u < S; u++) {
+                const int pos = s + prefix_popc(m[u]);
+                if (hit[u] && pos < K) h[pos] = base + u * 64 + lane;
+                s += __popcll(m[u]);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < S; u++) { px[u] = nx[u]; py[u] = ny[u]; pz[u] = nz[u]; }
+        }
+    }
+    const int cnt = s < K ? s : K;
+    if (lane == 0) {
+        nnCount[row] = cnt;
+        if (s == 0) *flag = 1;              // this query takes a second pass in the reference: the chain kernel redoes the call
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int slot = lane; slot < K; slot += 64) {
+        int id = 0, bin = 0;
+        float dist = 0.0f;
+        if (slot < cnt) {
+            id = h[slot];
+            const float dx = db[(size_t)id * 3] - qx;
+            const float dy = db[(size_t)id * 3 + 1] - qy;
+            const float dz = db[(size_t)id * 3 + 2] - qz;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;   // tf_nnquery_gpu.cu:45-46
+            dist = sqrtf(sqrtf(d2));                          // :47 then :54 — sqrt of the distance
+            if (FUSE) {
+                if (fx.filt != nullptr)
+                    bin = fx.ocml ? sphere_bin<true>(dx, dy, dz, dist, fx.radius, fx.n, fx.p, fx.q)
+                                  : sphere_bin<false>(dx, dy, dz, dist, fx.radius, fx.n, fx.p, fx.q);
+                if (fx.deg != nullptr) {
+                    fx.slotPos[row * K + slot] = atomicAdd(&fx.deg[((size_t)b * N + id) * fx.F + bin], 1);
+                    fx.binUsed[bin] = 1;          // benign race: every writer stores 1
+                }
+            }
+        }
+        nnIndex[row * K + slot] = id;                          // unused slots read 0
+        nnDist[row * K + slot] = dist;
+        if (FUSE && fx.filt != nullptr) fx.filt[row * K + slot] = bin;
+    }
+}
+
 static std::atomic<long long> g_grid_launches{0};
 
 int nngrid_search(int B, int N, int M, int K, float radius, int fixed, const float* database, const float* query, int* nn_index,
@@ -391,7 +495,9 @@ int nngrid_search(int B, int N, int M, int K, float radius, int fixed, const flo
     // worth it from ~4 M point pairs per cloud (below, the chain kernel's scan of the whole cloud from LDS is as fast as the
     // grid's build + search: 2048 x 512 measured 60 vs 68 us); the sorted hit lists hold 16-bit indices; the chains must not
     // carry their radius from cloud to cloud (B <= 32 reference blocks)
-    if (N < 1024 || N > 65536 || M < 64 || (long long)N * M < (1LL << 22) || K > kGridMaxK || (!fixed && B > kRefGrid)) return 0;
+    if (N < 1024 || N > 65536 || M < 64 || M > kMaxPositions * kRefBlock || (long long)N * M < (1LL << 22) || K > kGridMaxK ||
+        (!fixed && B > kRefGrid))
+        return 0;
     // chain positions whose radius stays <= 2 r_0: the later ones find nn_sample hits early in the chain kernel's ascending
     // scan and would overflow the lists here
     int npos = 1;
@@ -405,7 +511,7 @@ int nngrid_search(int B, int N, int M, int K, float radius, int fixed, const flo
         const int have = (M + kRefBlock - 1) / kRefBlock;
         if (npos > have) npos = have;
     }
-    const size_t hdrBytes = 256 + sizeof(GridHdr) * (size_t)B;
+    const size_t hdrBytes = 1024 + sizeof(GridHdr) * (size_t)B;
     const size_t csBytes = sizeof(int) * (size_t)B * (kGridMaxCells + 1);
     const size_t ptBytes = sizeof(float4) * (size_t)B * N;
     const size_t qoBytes = sizeof(int) * (size_t)B * M;
@@ -415,7 +521,7 @@ int nngrid_search(int B, int N, int M, int K, float radius, int fixed, const flo
     if (ws == nullptr) return 0;
     int* flag = (int*)ws;
     GridRadii* radii = (GridRadii*)(ws + 64);
-    GridHdr* hdr = (GridHdr*)(ws + 256);
+    GridHdr* hdr = (GridHdr*)(ws + 1024);
     int* cellStart = (int*)(ws + ((hdrBytes + a16) & ~a16));
     float4* pts = (float4*)((unsigned char*)cellStart + ((csBytes + a16) & ~a16));
     int* qorder = (int*)((unsigned char*)pts + ptBytes);
@@ -440,11 +546,23 @@ int nngrid_search(int B, int N, int M, int K, float radius, int fixed, const flo
     } while (0)
     if (fuse != nullptr) SPH3D_GRID(true); else SPH3D_GRID(false);
 #undef SPH3D_GRID
+    if (!fixed && M > npos * kRefBlock) {
+        // the later positions: early-stopping scans, a wave per query
+        const int j0 = npos * kRefBlock;
+        const int dparts = (M - j0 + 3) / 4;
+        const size_t dlds = sizeof(int) * 4 * (size_t)K;
+        if (fuse != nullptr)
+            hipLaunchKernelGGL(nndense_kernel<true>, dim3(xcd_grid(B, dparts)), dim3(256), dlds, st, B, N, M, K, j0, dparts, fx, flag,
+                               radii, hdr, database, query, nn_index, nn_count, nn_dist);
+        else
+            hipLaunchKernelGGL(nndense_kernel<false>, dim3(xcd_grid(B, dparts)), dim3(256), dlds, st, B, N, M, K, j0, dparts, fx, flag,
+                               radii, hdr, database, query, nn_index, nn_count, nn_dist);
+    }
     rc = check_launch("nngrid_search");
     if (rc) return rc;
     g_grid_launches.fetch_add(1, std::memory_order_relaxed);
     *gate = flag;
-    *grid_done = fixed ? (1 << 20) : npos;
+    *grid_done = 1 << 20;          // every query is done unless the flag is up
     return 1;
 }
 
