@@ -30,6 +30,8 @@ if tr:
         for (k, g, w), v in rows[:120]:
             f.write('"%s",%s,%s,%d,%.1f,%.1f,%.1f,%.1f\n' % (k, g, w, len(v), sum(v), sum(v) / len(v), min(v), max(v)))
 PY
+# PROFILE_LIGHT=1: skip the conv / GEMM counter passes (their kernels did not change since the last full run)
+if [ -z "$PROFILE_LIGHT" ]; then
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $pass | cut -c1-3)
   for cfg in "fwd:LDS=" "fwdl:LDS=1" "bwd:LDS="; do
@@ -56,14 +58,16 @@ for cfg in "nn:KIND=nn SHAPE=131072,256,128" "tn:KIND=tn SHAPE=32768,1024,128" "
     bash tools/gpu_pmc3.sh ${TAG}_gemm${name}_$n tools/exp_gemm_pmc.py "$env" "$pass" gemm | tail -3
   done
 done
-# neighbour search (level-0 plain search, 16 x 8192, K = 64): instruction mix of the in-tree kernel and, when a library built
+fi
+# neighbour search (level-0 plain search, 16 x 8192, K = 64): instruction mix of the in-tree kernels (grid build / order / search,
+# dense scan; SPH3D_NNGRID=0: the chain kernel alone) and, when a library built
 # with the previous scan is present (sph3d_gcn_amd/csrc/libsph3d_nnbefore.so), of that one.  To build it: `git show 382d868~1:sph3d_gcn_amd/csrc/nnquery.hip`
 # into a scratch directory next to copies of common.hpp / sphere_bin.hpp, hipcc -c it with the Makefile's flags and link it with the
 # in-tree objects of the other sources (the library is git-ignored and was not kept)
-for cfg in "after:" "before:SPH3D_LIB=$GRAFT_REPO_ROOT/sph3d_gcn_amd/csrc/libsph3d_nnbefore.so"; do
+for cfg in "after:" "chain:SPH3D_NNGRID=0" "before:SPH3D_LIB=$GRAFT_REPO_ROOT/sph3d_gcn_amd/csrc/libsph3d_nnbefore.so"; do
   name=${cfg%%:*}; env=${cfg#*:}
   [ "$name" = "before" ] && [ ! -f $GRAFT_REPO_ROOT/sph3d_gcn_amd/csrc/libsph3d_nnbefore.so ] && continue
-  bash tools/gpu_pmc3.sh ${TAG}_nnquery_$name tools/exp_nn_pmc.py "NN=plain $env" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH GRBM_GUI_ACTIVE" nnquery | tail -2
+  bash tools/gpu_pmc3.sh ${TAG}_nnquery_$name tools/exp_nn_pmc.py "NN=plain $env" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH GRBM_GUI_ACTIVE" nn | tail -6
 done
 # one flat CSV per counter pass next to the summaries (what gets copied into profiles/)
 for d in $OUT/pmc_${TAG}_*; do
