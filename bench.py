@@ -520,7 +520,7 @@ def secondary_main(args, rank, world, dev, pinned_cpus):
                           "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                           "cpus_per_rank": pinned_cpus},
                "dist": {"per_rank_ms_per_step": [round(x / args.steps * 1e3, 3) for x in per_rank_s]},
-               "loss": round(float(loss), 5), "families_ms_per_step": families, "roofline": roofline, "kernels": kernels,
+               "loss": round(float(loss.detach()), 5), "families_ms_per_step": families, "roofline": roofline, "kernels": kernels,
                "cpu_baseline": None}
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -761,7 +761,7 @@ def main():
                      "allreduce_wait_host_ms_per_step": round(flat.stats["allreduce_wait_host_s"] / max(1, flat.stats["allreduce_calls"]) * 1e3, 4),
                      "note": "rank 0's counters; allreduce_wait_stream = HIP events around the wait in FlatGradAllReduce.all_reduce() "
                              "on the main stream during the %d event-pass steps (0 at one GPU: no collective is issued)" % ev_steps},
-            "loss": round(float(loss), 5),
+            "loss": round(float(loss.detach()), 5),
             "sph3d_calls_ms_per_step_summed_over_streams": round(sph3d_ms, 3),
             "families_ms_per_step": families,
             "roofline": roofline,
