@@ -32,7 +32,9 @@
 //
 // Measured (MI355X, S3DIS level 0, 16 x 8192 points, r_0 = 0.1, K = 64, fused with bins and segment counts;
 // tools/exp_nngrid.py): chain kernel alone 472 us; grid build 16 + query order + search of positions 0-4 147 + dense scan of
-// positions 5-7 165 = 342 us (both kernels VALU-bound: ~3400 and ~1600 wave instructions per wave).  Level 1 (16 x 2048, two
+// positions 5-7 155 = 335 us (both kernels VALU-bound; counters of the fused call: search 60.7 M VALU + 26.6 M SALU over
+// 20 480 waves, dense scan 69.3 M + 38.1 M over 12 288 waves of four queries, about half of it the output pass: two atan2f and
+// the reference's double-precision bin arithmetic per neighbour).  Level 1 (16 x 2048, two
 // positions, all from the grid): 84 -> 60 us.  In the training step (graph stream, beside the feature kernels) the fused graph
 // construction drops from 1.69 to 1.23 ms per step: 1767 -> 1788 blocks/s.
 #include <atomic>
@@ -42,6 +44,8 @@
 #include "nnquery.hpp"
 
 namespace sph3d {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kGridMaxCells = 8192;      // LDS histogram of the build kernels (32 KB: they must fit beside the step's other kernels)
 constexpr int kGridMinCells = 512;       // below this 27 cells are too large a share of the cloud
@@ -393,60 +397,84 @@ __global__ __launch_bounds__(64) void nngrid_search_kernel(
 // nn_sample hits after a fraction of the cloud — a WAVE per query walks the cloud 128 points per trip in index order and stops
 // there.  No chain state (the radius of position k is tabulated), every query independent: 49 152 waves at S3DIS level 0
 // where the chain kernel walks 1024 chains per cloud one query after the other.  K <= 256 slots in LDS per wave.
+constexpr int kDenseQ = 4;              // queries per wave: they share every trip's points
 template <bool FUSE>
 __global__ __launch_bounds__(256) void nndense_kernel(
     int B, int N, int M, int K, int j0, int parts, GraphFuse fx, int* __restrict__ flag, const GridRadii* __restrict__ radii,
     const GridHdr* __restrict__ hdr, const float* __restrict__ database, const float* __restrict__ query,
     int* __restrict__ nnIndex, int* __restrict__ nnCount, float* __restrict__ nnDist)
 {
-    extern __shared__ int lhits[];                    // [4][K]
+    extern __shared__ int lhits[];                    // [4 waves][kDenseQ][K]
     int b, part;
     xcd_decode((int)blockIdx.x, B, parts, b, part);
     if (b < 0 || hdr[b].nx == 0) return;              // (a cloud the grid gave up on: the chain kernel recomputes the call)
     const int lane = lane_id(), w = uniform((int)threadIdx.x >> 6);
-    const int j = j0 + part * 4 + w;
-    if (j >= M) return;
-    int* h = lhits + w * K;
+    const int jw = j0 + (part * 4 + w) * kDenseQ;     // the wave's first query; its queries share a chain position (1024 | j0)
+    if (jw >= M) return;
+    int* h = lhits + w * kDenseQ * K;
     const float* db = database + (size_t)b * N * 3;
-    const size_t row = (size_t)b * M + j;
-    const float qx = query[row * 3], qy = query[row * 3 + 1], qz = query[row * 3 + 2];
-    const float T = radii->thr[j / kRefBlock];
-    int s = 0;
-    // four strips of 64 points per trip, and the next trip's twelve loads are issued before this trip's points are tested:
-    // the walk is a chain of L2 round trips otherwise (one trip in flight: 164 us for S3DIS level 0's three late positions)
+    const float T = radii->thr[jw / kRefBlock];
+    float qx[kDenseQ], qy[kDenseQ], qz[kDenseQ];
+    int s[kDenseQ];
+    bool live[kDenseQ];
+#pragma unroll
+    for (int c = 0; c < kDenseQ; c++) {
+        live[c] = jw + c < M;
+        const size_t row = (size_t)b * M + (live[c] ? jw + c : jw);
+        qx[c] = query[row * 3]; qy[c] = query[row * 3 + 1]; qz[c] = query[row * 3 + 2];
+        s[c] = live[c] ? 0 : K;                       // a query past the end is closed from the start
+    }
+    // four strips of 64 points per trip, and the next trip's twelve loads are issued before this trip's points are tested
     constexpr int S = 4;
     float px[S], py[S], pz[S];
     auto fetch = [&](int base, float* x, float* y, float* z) {
 #pragma unroll
         for (int u = 0; u < S; u++) {
             const int i = base + u * 64 + lane;
-            const int c = i < N ? i : N - 1;                    // points past the end: clamped here, masked at the test
-            x[u] = db[(size_t)c * 3]; y[u] = db[(size_t)c * 3 + 1]; z[u] = db[(size_t)c * 3 + 2];
+            const int cl = i < N ? i : N - 1;                   // points past the end: clamped here, masked at the test
+            x[u] = db[(size_t)cl * 3]; y[u] = db[(size_t)cl * 3 + 1]; z[u] = db[(size_t)cl * 3 + 2];
         }
     };
     fetch(0, px, py, pz);
-    for (int base = 0; base < N && s < K; base += 64 * S) {
+    for (int base = 0; base < N; base += 64 * S) {
+        bool open = false;
+#pragma unroll
+        for (int c = 0; c < kDenseQ; c++) open = open || s[c] < K;
+        if (!open) break;
         float nx[S], ny[S], nz[S];
         const bool more = base + 64 * S < N;
         if (more) fetch(base + 64 * S, nx, ny, nz);
-        unsigned long long m[S];
-        bool hit[S];
-        unsigned long long any = 0ull;
 #pragma unroll
-        for (int u = 0; u < S; u++) {
-            const float dx = px[u] - qx, dy = py[u] - qy, dz = pz[u] - qz;
-            const float d2 = (dx * dx + dy * dy) + dz * dz;        // tf_nnquery_gpu.cu:45-46
-            hit[u] = base + u * 64 + lane < N && d2 < T;
-            m[u] = __builtin_amdgcn_ballot_w64(hit[u]);
-            any |= m[u];
-        }
-        if (any != 0ull) {
-            // ascending index: a strip's hits take their slots before the next strip's
+        for (int c = 0; c < kDenseQ; c++) {
+            if (s[c] < K) {                                       // wave-uniform
+                unsigned long long m[S];
+                bool hit[S];
+                unsigned long long any = 0ull;
+                // two strips per packed instruction (v_pk_add / v_pk_mul_f32: IEEE per component, no contraction — the
+                // same roundings as the scalar form)
 #pragma unroll
-            for (int u = 0; u < S; u++) {
-                const int pos = s + prefix_popc(m[u]);
-                if (hit[u] && pos < K) h[pos] = base + u * 64 + lane;
-                s += __popcll(m[u]);
+                for (int u = 0; u < S; u += 2) {
+                    const f32x2 dx = f32x2{px[u], px[u + 1]} - qx[c];
+                    const f32x2 dy = f32x2{py[u], py[u + 1]} - qy[c];
+                    const f32x2 dz = f32x2{pz[u], pz[u + 1]} - qz[c];
+                    const f32x2 d2 = (dx * dx + dy * dy) + dz * dz;        // tf_nnquery_gpu.cu:45-46
+                    hit[u] = base + u * 64 + lane < N && d2.x < T;
+                    hit[u + 1] = base + (u + 1) * 64 + lane < N && d2.y < T;
+                    m[u] = __builtin_amdgcn_ballot_w64(hit[u]);
+                    m[u + 1] = __builtin_amdgcn_ballot_w64(hit[u + 1]);
+                    any |= m[u] | m[u + 1];
+                }
+                if (any != 0ull) {
+                    // ascending index: a strip's hits take their slots before the next strip's
+                    int sc = s[c];
+#pragma unroll
+                    for (int u = 0; u < S; u++) {
+                        const int pos = sc + prefix_popc(m[u]);
+                        if (hit[u] && pos < K) h[c * K + pos] = base + u * 64 + lane;
+                        sc += __popcll(m[u]);
+                    }
+                    s[c] = sc;
+                }
             }
         }
         if (more) {
@@ -454,36 +482,41 @@ __global__ __launch_bounds__(256) void nndense_kernel(
             for (int u = 0; u < S; u++) { px[u] = nx[u]; py[u] = ny[u]; pz[u] = nz[u]; }
         }
     }
-    const int cnt = s < K ? s : K;
-    if (lane == 0) {
-        nnCount[row] = cnt;
-        if (s == 0) *flag = 1;              // this query takes a second pass in the reference: the chain kernel redoes the call
-    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (int slot = lane; slot < K; slot += 64) {
-        int id = 0, bin = 0;
-        float dist = 0.0f;
-        if (slot < cnt) {
-            id = h[slot];
-            const float dx = db[(size_t)id * 3] - qx;
-            const float dy = db[(size_t)id * 3 + 1] - qy;
-            const float dz = db[(size_t)id * 3 + 2] - qz;
-            const float d2 = (dx * dx + dy * dy) + dz * dz;   // tf_nnquery_gpu.cu:45-46
-            dist = sqrtf(sqrtf(d2));                          // :47 then :54 — sqrt of the distance
-            if (FUSE) {
-                if (fx.filt != nullptr)
-                    bin = fx.ocml ? sphere_bin<true>(dx, dy, dz, dist, fx.radius, fx.n, fx.p, fx.q)
-                                  : sphere_bin<false>(dx, dy, dz, dist, fx.radius, fx.n, fx.p, fx.q);
-                if (fx.deg != nullptr) {
-                    fx.slotPos[row * K + slot] = atomicAdd(&fx.deg[((size_t)b * N + id) * fx.F + bin], 1);
-                    fx.binUsed[bin] = 1;          // benign race: every writer stores 1
+#pragma unroll 1
+    for (int c = 0; c < kDenseQ; c++) {
+        if (!live[c]) break;
+        const size_t row = (size_t)b * M + jw + c;
+        const int cnt = s[c] < K ? s[c] : K;
+        if (lane == 0) {
+            nnCount[row] = cnt;
+            if (s[c] == 0) *flag = 1;       // this query takes a second pass in the reference: the chain kernel redoes the call
+        }
+        for (int slot = lane; slot < K; slot += 64) {
+            int id = 0, bin = 0;
+            float dist = 0.0f;
+            if (slot < cnt) {
+                id = h[c * K + slot];
+                const float dx = db[(size_t)id * 3] - qx[c];
+                const float dy = db[(size_t)id * 3 + 1] - qy[c];
+                const float dz = db[(size_t)id * 3 + 2] - qz[c];
+                const float d2 = (dx * dx + dy * dy) + dz * dz;   // tf_nnquery_gpu.cu:45-46
+                dist = sqrtf(sqrtf(d2));                          // :47 then :54 — sqrt of the distance
+                if (FUSE) {
+                    if (fx.filt != nullptr)
+                        bin = fx.ocml ? sphere_bin<true>(dx, dy, dz, dist, fx.radius, fx.n, fx.p, fx.q)
+                                      : sphere_bin<false>(dx, dy, dz, dist, fx.radius, fx.n, fx.p, fx.q);
+                    if (fx.deg != nullptr) {
+                        fx.slotPos[row * K + slot] = atomicAdd(&fx.deg[((size_t)b * N + id) * fx.F + bin], 1);
+                        fx.binUsed[bin] = 1;          // benign race: every writer stores 1
+                    }
                 }
             }
+            nnIndex[row * K + slot] = id;                          // unused slots read 0
+            nnDist[row * K + slot] = dist;
+            if (FUSE && fx.filt != nullptr) fx.filt[row * K + slot] = bin;
         }
-        nnIndex[row * K + slot] = id;                          // unused slots read 0
-        nnDist[row * K + slot] = dist;
-        if (FUSE && fx.filt != nullptr) fx.filt[row * K + slot] = bin;
     }
 }
 
@@ -549,8 +582,8 @@ int nngrid_search(int B, int N, int M, int K, float radius, int fixed, const flo
     if (!fixed && M > npos * kRefBlock) {
         // the later positions: early-stopping scans, a wave per query
         const int j0 = npos * kRefBlock;
-        const int dparts = (M - j0 + 3) / 4;
-        const size_t dlds = sizeof(int) * 4 * (size_t)K;
+        const int dparts = (M - j0 + 4 * kDenseQ - 1) / (4 * kDenseQ);
+        const size_t dlds = sizeof(int) * 4 * kDenseQ * (size_t)K;
         if (fuse != nullptr)
             hipLaunchKernelGGL(nndense_kernel<true>, dim3(xcd_grid(B, dparts)), dim3(256), dlds, st, B, N, M, K, j0, dparts, fx, flag,
                                radii, hdr, database, query, nn_index, nn_count, nn_dist);
