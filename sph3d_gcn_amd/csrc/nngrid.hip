@@ -62,8 +62,6 @@ struct GridRadii {
     float thr[kMaxPositions], rk[kMaxPositions];      // exact threshold T(r_k) and radius of chain position k
 };
 
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
 // cell coordinate along one axis; NaN / huge values land in a valid cell (the distance test rejects them)
 __device__ __forceinline__ int cell_of(float v, float lo, float invh, int n)
 {
@@ -159,7 +157,9 @@ __global__ __launch_bounds__(1024) void nngrid_build_kernel(
     __syncthreads();
     // the radius of position k and the exact threshold of its predicate: wave k computes T(r_k) (wave-cooperative search)
     if (b == 0) {
-        const int have = fixed ? 1 : (M + kRefBlock - 1) / kRefBlock;     // positions in use (<= kMaxPositions)
+        // positions in use (<= kMaxPositions): the clouds b, b + 32, ... share a reference block, whose chains go on from cloud
+        // to cloud (position = (b / 32) * slices per cloud + j / 1024)
+        const int have = fixed ? 1 : (((int)gridDim.x + kRefGrid - 1) / kRefGrid) * ((M + kRefBlock - 1) / kRefBlock);
         for (int k0 = w; k0 < have; k0 += 16) {
             float rk = radius;
             for (int k = 0; k < k0; k++) rk = (float)((double)rk + 0.05);  // tf_nnquery_gpu.cu:59, the chain kernel's sequence
@@ -196,7 +196,13 @@ __global__ __launch_bounds__(1024) void nngrid_build_kernel(
         H.minx = l3[0]; H.miny = l3[1]; H.minz = l3[2];
         H.invh = 1.0f / h;
         H.nx = ok ? n3[0] : 0; H.ny = n3[1]; H.nz = n3[2];
-        H.nq = fixed ? M : (M < npos * kRefBlock ? M : npos * kRefBlock);
+        {
+            // the queries of this cloud the grid takes: its slices whose chain position is below npos
+            const int S = (M + kRefBlock - 1) / kRefBlock;
+            int sl = npos - (b / kRefGrid) * S;
+            sl = sl < 0 ? 0 : (sl > S ? S : sl);
+            H.nq = fixed ? M : (M < sl * kRefBlock ? M : sl * kRefBlock);
+        }
         hdr[b] = H;
         if (!ok) *flag = 1;
     }
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(64) void nngrid_search_kernel(
         qid = qorder[(size_t)b * M + qpos];
         const float* q = query + ((size_t)b * M + qid) * 3;
         qx = q[0]; qy = q[1]; qz = q[2];
-        kq = fixed ? 0 : qid / kRefBlock;
+        kq = fixed ? 0 : (b / kRefGrid) * ((M + kRefBlock - 1) / kRefBlock) + qid / kRefBlock;
     }
     const int nx = H.nx, ny = H.ny, nz = H.nz;
     const int cx = cell_of(qx, H.minx, H.invh, nx), cy = cell_of(qy, H.miny, H.invh, ny), cz = cell_of(qz, H.minz, H.invh, nz);
@@ -413,7 +419,8 @@ __global__ __launch_bounds__(256) void nndense_kernel(
     if (jw >= M) return;
     int* h = lhits + w * kDenseQ * K;
     const float* db = database + (size_t)b * N * 3;
-    const float T = radii->thr[jw / kRefBlock];
+    if (jw < hdr[b].nq) return;                       // this cloud's early positions: the grid's
+    const float T = radii->thr[(b / kRefGrid) * ((M + kRefBlock - 1) / kRefBlock) + jw / kRefBlock];
     float qx[kDenseQ], qy[kDenseQ], qz[kDenseQ];
     int s[kDenseQ];
     bool live[kDenseQ];
@@ -526,13 +533,15 @@ int nngrid_search(int B, int N, int M, int K, float radius, int fixed, const flo
                   int* nn_count, float* nn_dist, const GraphFuse* fuse, hipStream_t st, const int** gate, int* grid_done)
 {
     // worth it from ~4 M point pairs per cloud (below, the chain kernel's scan of the whole cloud from LDS is as fast as the
-    // grid's build + search: 2048 x 512 measured 60 vs 68 us); the sorted hit lists hold 16-bit indices; the chains must not
-    // carry their radius from cloud to cloud (B <= 32 reference blocks)
+    // grid's build + search: 2048 x 512 measured 60 vs 68 us); the sorted hit lists hold 16-bit indices; with more than 32 clouds
+    // (two clouds per reference block: its chains go on from one to the next) every thread must visit the same number of
+    // queries per cloud, so that a query's position is a function of (cloud, j) alone
     if (N < 1024 || N > 65536 || M < 64 || M > kMaxPositions * kRefBlock || (long long)N * M < (1LL << 22) || K > kGridMaxK ||
-        (!fixed && B > kRefGrid))
+        (!fixed && B > kRefGrid && ((M >= kRefBlock && M % kRefBlock != 0) ||
+                                    ((B + kRefGrid - 1) / kRefGrid) * ((M + kRefBlock - 1) / kRefBlock) > kMaxPositions)))
         return 0;
-    // chain positions whose radius stays <= 2 r_0: the later ones find nn_sample hits early in the chain kernel's ascending
-    // scan and would overflow the lists here
+    // chain positions whose radius stays <= 3 r_0 go through the grid; the later ones find nn_sample hits early in an ascending
+    // scan (nndense_kernel)
     int npos = 1;
     if (!fixed) {
         float rk = radius;
@@ -541,7 +550,7 @@ int nngrid_search(int B, int N, int M, int K, float radius, int fixed, const flo
             if (!(rk <= kGridReach * radius)) break;
             npos++;
         }
-        const int have = (M + kRefBlock - 1) / kRefBlock;
+        const int have = ((B + kRefGrid - 1) / kRefGrid) * ((M + kRefBlock - 1) / kRefBlock);      // positions in use
         if (npos > have) npos = have;
     }
     const size_t hdrBytes = 1024 + sizeof(GridHdr) * (size_t)B;
@@ -579,9 +588,16 @@ int nngrid_search(int B, int N, int M, int K, float radius, int fixed, const flo
     } while (0)
     if (fuse != nullptr) SPH3D_GRID(true); else SPH3D_GRID(false);
 #undef SPH3D_GRID
-    if (!fixed && M > npos * kRefBlock) {
-        // the later positions: early-stopping scans, a wave per query
-        const int j0 = npos * kRefBlock;
+    // the later positions: early-stopping scans.  The first query any cloud leaves to them (the clouds of the last block round
+    // start at the highest positions): the kernel skips the part of a cloud that its grid share covers
+    int j0 = M;
+    if (!fixed) {
+        const int S = (M + kRefBlock - 1) / kRefBlock;
+        int sl = npos - ((B - 1) / kRefGrid) * S;
+        sl = sl < 0 ? 0 : (sl > S ? S : sl);
+        j0 = sl * kRefBlock < M ? sl * kRefBlock : M;
+    }
+    if (j0 < M) {
         const int dparts = (M - j0 + 4 * kDenseQ - 1) / (4 * kDenseQ);
         const size_t dlds = sizeof(int) * 4 * kDenseQ * (size_t)K;
         if (fuse != nullptr)

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void nnquery_sphere_kernel(
         r[c] = radius0;
         kpos[c] = kstart;
     }
-    for (int k = 0; k < kstart; k++) {                      // kstart > 0 only without carries between clouds (B <= 32, not `fixed`)
+    for (int k = 0; k < kstart; k++) {                      // (kstart is 0 or past the last query)
 #pragma unroll
         for (int c = 0; c < CPW; c++) r[c] = (float)((double)r[c] + 0.05);
     }

@@ -84,8 +84,19 @@ def test_queries_without_neighbours_hand_the_call_to_the_chain_kernel(dev):
     assert torch.equal(i0, i1) and torch.equal(c0, c1) and torch.equal(d0, d1)
 
 
-def test_batches_beyond_32_clouds_and_small_shapes_keep_the_chain_kernel(dev):
-    db = _cloud("uniform", 33, 2048, seed=5)            # clouds 0 and 32 share a reference block: the radius is carried over
+def test_more_than_32_clouds_carry_the_chain_position_from_cloud_to_cloud(dev):
+    """clouds b and b + 32 share a reference block: the second one's queries sit at the positions behind the first one's"""
+    db = _cloud("uniform", 40, 2048, seed=5)            # positions 0-1 in clouds 0-31, 2-3 in clouds 32-39
+    _check(dev, db, db, 0.08, 8)
+    db = _cloud("s3dis", 70, 2048, seed=5)              # three clouds per block: up to position 5 (r = 0.45 at r0 = 0.2)
+    _check(dev, db, db, 0.2, 64)
+    db = _cloud("s3dis", 40, 4096, seed=6)
+    q = np.ascontiguousarray(db[:, :1024])              # pooling-like, one query per thread and cloud: position = b / 32
+    _check(dev, db, q, 0.1, 32)
+
+
+def test_shapes_the_grid_does_not_take_keep_the_chain_kernel(dev):
+    db = _cloud("uniform", 33, 2100, seed=5)            # > 32 clouds with a ragged last slice: positions differ per thread
     _check(dev, db, db, 0.08, 8, expect_grid=False)
     db = _cloud("uniform", 2, 1000, seed=6)             # fewer than 1024 points
     _check(dev, db, db, 0.1, 16, expect_grid=False)
