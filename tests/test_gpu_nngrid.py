@@ -139,3 +139,23 @@ def test_fused_graph_with_bins_and_counts_equals_the_separate_ops(dev):
         finally:
             tf_buildkernel.set_atan2("shared")
         assert torch.equal(i0, i1) and torch.equal(c0, c1) and torch.equal(d0, d1) and torch.equal(f0, f1)
+
+
+def test_two_streams_search_at_the_same_time_with_their_own_grids(dev):
+    """the grid lives in a library-owned buffer PER STREAM: searches queued on two streams at once must not share it"""
+    a = _t(_cloud("s3dis", 4, 4096, seed=21), dev)
+    b = _t(_cloud("uniform", 4, 4096, seed=22), dev)
+    want_a = tf_nnquery.build_sphere_neighbor(a, a, 0.1, None, 32)
+    want_b = tf_nnquery.build_sphere_neighbor(b, b, 0.07, None, 32)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    for _ in range(3):
+        got = []
+        for _rep in range(4):                               # interleaved launches, several in flight per stream
+            with torch.cuda.stream(s1):
+                got.append((tf_nnquery.build_sphere_neighbor(a, a, 0.1, None, 32), want_a))
+            with torch.cuda.stream(s2):
+                got.append((tf_nnquery.build_sphere_neighbor(b, b, 0.07, None, 32), want_b))
+        torch.cuda.synchronize()
+        for g, w in got:
+            assert all(torch.equal(x, y) for x, y in zip(g, w))
