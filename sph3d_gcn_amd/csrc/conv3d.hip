@@ -385,15 +385,16 @@ constexpr int kBwdTPointsPerWG = 64;     // measured: 256 -> 1.90 ms, 128 -> 1.1
 #ifndef SPH3D_BWD_NL
 #define SPH3D_BWD_NL 2      // measured at C = 64, r = 2, level 0: 2 loads (4 edges) per batch 0.532 ms, 4 loads 0.631, one row per load 0.589
 #endif
-// HALF (CR == 128, V == 4): a grad_out row is 32 lanes wide, so the two halves of the wave take ALTERNATE edges of
+// PARTS = 2 (CR <= 128, V == 4): a grad_out row is at most 32 lanes wide, so the two halves of the wave take ALTERNATE edges of
 // a segment (one wave load = two rows) and keep separate partial sums, added across the halves once per source
-// (grad_input) / once per launch (the filter accumulators).
+// (grad_input) / once per launch (the filter accumulators).  PARTS = 4 (CR <= 64): four quarter waves, four rows per load
+// (the ModelNet plan's 64-output layers: half of the lanes idle otherwise).
 // COMPACT: the accumulator table has one row per ACTIVE bin of the graph (active_bins = [count, ascending list], written by
 // sph3d_graph_transpose): with the reference's sqrt-distance quirk the inner radial shell is empty at small radii
 // (SURVEY §0.5), so at S3DIS levels 0-2 only 17 of the 33 bins ever occur: 68 accumulator VGPRs instead of 132, four
 // workgroups per CU instead of three, and a 17- instead of 33-iteration segment loop.  The host cannot know the count
 // without a device->host sync, so BOTH variants are launched and each returns at once unless the count is in its range.
-template <int R, int V, int MAXF, bool HALF, bool COMPACT>
+template <int R, int V, int MAXF, int PARTS, bool COMPACT>
 __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t_vec(
     int B, int N, int M, int F, int C, int W, int parts, int nslices,
     const int* __restrict__ offsets, const int* __restrict__ entKey, const float* __restrict__ entScale,
@@ -435,8 +436,10 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
     const int wave = uniform((int)threadIdx.x >> 6);
     const int lane = lane_id();
     const int stride = W * kBwdTWaves;          // waves of this XCD that sweep a cloud side by side
-    const int half = HALF ? (lane >> 5) : 0;
-    const int cl0 = (HALF ? (lane & 31) : lane) * V;
+    constexpr bool HALF = PARTS > 1;                              // the wave is split into PARTS groups of 64 / PARTS lanes
+    constexpr int PL = 64 / PARTS;                                // lanes per group = row width / V
+    const int half = HALF ? (lane / PL) : 0;                      // the lane's group
+    const int cl0 = (HALF ? (lane % PL) : lane) * V;
     const bool act = cl0 < SL;
     const int cin0 = (slice0 + cl0) / R;
     // per-lane gradient-of-filter accumulators, one row per bin; every index below is a compile-time constant
@@ -540,14 +543,14 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
                         constexpr int NL = SPH3D_BWD_NL;          // wave loads per batch = 2 * NL edges
                         const float svh = ((unsigned)(lane - e0) < (unsigned)(e1 - e0)) ? sv : 0.f;
                         // (exact-count last batches, which pay in the full-wave branch, measured no gain here: 0.305 vs 0.319 ms)
-                        for (int e = e0; e < e1; e += 2 * NL) {
+                        for (int e = e0; e < e1; e += PARTS * NL) {
                             const int a4 = ((e + half) << 2);
                             unsigned ko[NL];
                             float sc[NL];
 #pragma unroll
                             for (int u = 0; u < NL; u++) {
-                                ko[u] = (unsigned)__builtin_amdgcn_ds_bpermute(a4 + 8 * u, (int)kel);
-                                sc[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(a4 + 8 * u, __float_as_int(svh)));
+                                ko[u] = (unsigned)__builtin_amdgcn_ds_bpermute(a4 + 4 * PARTS * u, (int)kel);
+                                sc[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(a4 + 4 * PARTS * u, __float_as_int(svh)));
                             }
                             float g[NL][V];
 #pragma unroll
@@ -609,7 +612,10 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
         }   // chunks of 64 in-edges
         if (HALF) {
 #pragma unroll
-            for (int v = 0; v < V; v++) gi[v] += __shfl_xor(gi[v], 32);
+            for (int v = 0; v < V; v++) {
+                gi[v] += __shfl_xor(gi[v], 32);
+                if (PARTS == 4) gi[v] += __shfl_xor(gi[v], 16);
+            }
         }
         if (act && half == 0) {
             float* gp = &gin[((size_t)b * N + n) * Cs + cin0];
@@ -631,7 +637,10 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
 #pragma unroll
         for (int i = 0; i < MAXF; i++)
 #pragma unroll
-            for (int v = 0; v < V; v++) acc[i][v] += __shfl_xor(acc[i][v], 32);
+            for (int v = 0; v < V; v++) {
+                acc[i][v] += __shfl_xor(acc[i][v], 32);
+                if (PARTS == 4) acc[i][v] += __shfl_xor(acc[i][v], 16);
+            }
     }
     // workgroup reduction of the per-wave accumulators: waves take turns on one [F][SL] LDS table
     __syncthreads();                 // everyone is done reading lfilt
@@ -948,7 +957,7 @@ extern "C" size_t sph3d_depthwise_conv3d_grad_t_workspace(int B, int N, int F, i
 
 constexpr int kCompactBins = 17;     // accumulator rows of the compact variant
 
-template <int R, int V, int MAXF, bool HALF>
+template <int R, int V, int MAXF, int PARTS>
 static int launch_bwd_t_vec(int B, int N, int M, int F, int C, const int* offsets, const int* ent_key,
                             const float* ent_scale, const int* order, const int* active_bins, const float* input,
                             const float* filter, const float* grad_output, float* grad_input, float* grad_filter,
@@ -963,8 +972,8 @@ static int launch_bwd_t_vec(int B, int N, int M, int F, int C, const int* offset
     const size_t lds = (size_t)F * SLmax * sizeof(float);
     // the compact launch exists for the 4-channels-per-lane plans with at most 63 bins (one register of segment bounds)
     const bool compact = active_bins != nullptr && V == 4 && MAXF > kCompactBins && F <= 63;
-    auto kern = dwconv_bwd_t_vec<R, V, MAXF, HALF, false>;
-    auto kernc = dwconv_bwd_t_vec<R, V, (V == 4 ? kCompactBins : MAXF), HALF, (V == 4)>;
+    auto kern = dwconv_bwd_t_vec<R, V, MAXF, PARTS, false>;
+    auto kernc = dwconv_bwd_t_vec<R, V, (V == 4 ? kCompactBins : MAXF), PARTS, (V == 4)>;
     if (lds > 64 * 1024) {
         int rc = check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                            "conv3d: hipFuncSetAttribute");
@@ -1012,14 +1021,18 @@ extern "C" int sph3d_depthwise_conv3d_grad_t(int B, int N, int M, int F, int C, 
         }
         float* partial = (float*)workspace;
 #define SPH3D_GO(RR, VV, MF) \
-    return launch_bwd_t_vec<RR, VV, MF, false>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, active_bins, input, \
+    return launch_bwd_t_vec<RR, VV, MF, 1>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, active_bins, input, \
                                         filter, grad_output, grad_input, grad_filter, partial, st)
-        if (V == 4 && CR == 128 && r == 2)
-            return launch_bwd_t_vec<2, 4, 33, true>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, active_bins, input,
-                                                    filter, grad_output, grad_input, grad_filter, partial, st);
-        if (V == 4 && CR == 128 && r == 1)
-            return launch_bwd_t_vec<1, 4, 33, true>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, active_bins, input,
-                                                    filter, grad_output, grad_input, grad_filter, partial, st);
+        // rows of at most 128 (64) outputs: two half (four quarter) waves take alternate edges; a narrower row leaves lanes of
+        // each part idle, but fewer than the full-wave form would (the ModelNet plan's 36-, 64- and 68-channel layers)
+#define SPH3D_GO_PARTS(RR, PP) \
+    return launch_bwd_t_vec<RR, 4, 33, PP>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, active_bins, input, \
+                                           filter, grad_output, grad_input, grad_filter, partial, st)
+        if (V == 4 && CR <= 64 && r == 2) SPH3D_GO_PARTS(2, 4);
+        if (V == 4 && CR <= 64 && r == 1) SPH3D_GO_PARTS(1, 4);
+        if (V == 4 && CR <= 128 && r == 2) SPH3D_GO_PARTS(2, 2);
+        if (V == 4 && CR <= 128 && r == 1) SPH3D_GO_PARTS(1, 2);
+#undef SPH3D_GO_PARTS
         if (V == 4 && r == 2) SPH3D_GO(2, 4, 33);
         if (V == 4 && r == 1) SPH3D_GO(1, 4, 33);
         if (V == 2 && r == 2) SPH3D_GO(2, 2, 65);
@@ -1139,8 +1152,8 @@ extern "C" int sph3d_depthwise_conv3d_grad_t_cat(int B, int N, int M, int F, int
     }
     float* partial = (float*)workspace;
     if (r == 2)
-        return launch_bwd_t_vec<2, 4, 33, false>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, active_bins, input_a, filter,
+        return launch_bwd_t_vec<2, 4, 33, 1>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, active_bins, input_a, filter,
                                                  grad_output, grad_a, grad_filter, partial, st, input_b, grad_b, Ca);
-    return launch_bwd_t_vec<1, 4, 33, false>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, active_bins, input_a, filter,
+    return launch_bwd_t_vec<1, 4, 33, 1>(B, N, M, F, C, offsets, ent_key, ent_scale, source_order, active_bins, input_a, filter,
                                              grad_output, grad_a, grad_filter, partial, st, input_b, grad_b, Ca);
 }
