@@ -60,22 +60,29 @@ def normalize_xyz(points):
     return points / scale
 
 
-def get_model(points, is_training, config=None, dropout_generator=None):
-    """models/SPH3D_modelnet.py:33-107: points [B, N, 3] -> logits [B, num_cls]"""
+def get_model(points, is_training, config=None, dropout_generator=None, points_ready=None):
+    """models/SPH3D_modelnet.py:33-107: points [B, N, 3] -> logits [B, num_cls]
+    points_ready: optional event after which `points` is valid (GraphPlan: the plan of this step then overlaps the previous
+    step's backward pass instead of waiting for it)"""
     batch_size, num_point = points.shape[0], points.shape[1]
     end_points = {}
     assert num_point == config.num_input
-    if config.normalize:
-        points = normalize_xyz(points)
-    xyz = points
-    query = xyz.mean(dim=1, keepdim=True)                   # the global viewing point
     reuse = None
     # On the GPU the graph construction (same ops, arguments and results as the build_graph / spherical_kernel calls below) is
-    # issued ahead of the feature path on the sampling and graph streams, like the segmentation nets' (s3dis_net.GraphPlan)
+    # issued ahead of the feature path on the sampling and graph streams, like the segmentation nets' (s3dis_net.GraphPlan):
+    # the normalisation of the coordinates and the global viewing point (:35-44) are its first kernels there
     plan = None
-    if xyz.is_cuda and config.sample == 'FPS':
-        plan = GraphPlan(xyz.contiguous(), config, decoder=False, global_kernel=[8, 2, 1], global_query=query,
-                         prepare_input=False)
+    if points.is_cuda and config.sample == 'FPS':
+        plan = GraphPlan(points[:, :, 0:3], config, decoder=False, global_kernel=[8, 2, 1], global_query="centroid",
+                         prepare_input=False, points_ready=points_ready,
+                         xyz_transform=normalize_xyz if config.normalize else None)
+        xyz = plan.xyz0()
+        query = None
+    else:
+        if config.normalize:
+            points = normalize_xyz(points)
+        xyz = points
+        query = xyz.mean(dim=1, keepdim=True)               # the global viewing point
     net = s3g_util.pointwise_conv3d(xyz, config.mlp, 'mlp1', weight_decay=config.weight_decay,
                                     with_bn=config.with_bn, with_bias=config.with_bias, reuse=reuse,
                                     is_training=is_training)
@@ -159,9 +166,9 @@ class SPH3DModelNet(torch.nn.Module):
         self.config = copy.deepcopy(config) if config is not None else modelnet_config()
         self.store = s3g_util.VariableStore(device=device, seed=seed)
 
-    def forward(self, points, is_training=True, dropout_generator=None):
+    def forward(self, points, is_training=True, dropout_generator=None, points_ready=None):
         with s3g_util.variable_store(self.store):
-            return get_model(points, is_training, self.config, dropout_generator=dropout_generator)
+            return get_model(points, is_training, self.config, dropout_generator=dropout_generator, points_ready=points_ready)
 
     def loss(self, pred, label):
         """train_modelnet.py:162-164: classification loss + the weight-decay 'losses' collection + the BN regularisers

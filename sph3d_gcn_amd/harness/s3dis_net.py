@@ -99,12 +99,16 @@ class GraphPlan:
     On CPU tensors (oracle-backed tests) everything is built lazily on the spot."""
 
     def __init__(self, points, config, overlap=True, points_ready=None, decoder=True, global_kernel=None, global_radius=100.0,
-                 global_query=None, prepare_input=True, need_backward=None):
+                 global_query=None, prepare_input=True, need_backward=None, xyz_transform=None):
         """decoder=False: an encoder-only plan (the classification net); global_kernel: also the global graph of
         models/SPH3D_modelnet.py:83-93 (query = centroid of the last level's points, every remaining point a neighbour) with
         the bins of that kernel (global_query: the query points [B, 1, 3], default the centroid of the last level);
         need_backward (default: torch.is_grad_enabled()): also build the transposed graphs the gradients gather over;
         prepare_input=False: `points` are coordinates only (no S3DIS input features to prepare).
+        xyz_transform: a function of the raw coordinates (the classification net's unit-sphere normalisation) applied ON THE
+        SAMPLING STREAM before anything else: the plan is built on its result (xyz_layers[0]; `xyz0()` hands it to the feature
+        path), so that with points_ready the whole plan depends on the input batch alone.  global_query="centroid": the
+        global graph's query is the mean of those coordinates (models/SPH3D_modelnet.py:44), computed there as well.
         points_ready: optional event after which `points` is valid.  With it the two side streams wait only for the
         INPUT, not for everything queued on the main stream — so when the host runs ahead (it issues a step in about
         half the time the GPU needs), the sampling / graph construction of step t+1 overlaps the backward pass of step
@@ -149,15 +153,21 @@ class GraphPlan:
             # net's normalised coordinates may be freed by the caller while those kernels are still queued)
             points.record_stream(s_fps)
             points.record_stream(s_graph)
-            if global_query is not None:
+            if torch.is_tensor(global_query):
                 global_query.record_stream(s_graph)
             with torch.cuda.stream(s_fps):
                 # one contiguous copy of the coordinates for every op of the plan (the [:, :, 0:3] view made each
                 # neighbour search / binning / sampling call copy it again)
                 xyz = xyz.contiguous()
+                if xyz_transform is not None:
+                    xyz = xyz_transform(xyz).contiguous()
+                if isinstance(self.global_query, str):           # "centroid"
+                    self.global_query = xyz.mean(dim=1, keepdim=True)
+                    self.global_query.record_stream(s_graph)
                 self.xyz_layers[0] = xyz
                 ev_xyz = torch.cuda.Event()
                 ev_xyz.record(s_fps)
+                self._xyz_ev = ev_xyz
                 # the network's input features (centred coordinates + colours, models/SPH3D_s3dis.py:11-19,38-41) depend on the
                 # batch only: prepared here, ahead of the feature path (one reduction + four small kernels, 60 us of main-stream time)
                 if prepare_input:
@@ -177,7 +187,17 @@ class GraphPlan:
             with torch.cuda.stream(s_graph):
                 self._build_all(s_graph)
         else:
+            if xyz_transform is not None:
+                self.xyz_layers[0] = xyz_transform(xyz)
+            if isinstance(self.global_query, str):
+                self.global_query = self.xyz_layers[0].mean(dim=1, keepdim=True)
             self._sampling_chain(None)
+
+    def xyz0(self):
+        """the coordinates the plan was built on (after xyz_transform), ordered before the current stream's later work"""
+        if self.use_side:
+            self._sync(("xyz0",), self._xyz_ev, [self.xyz_layers[0]] + ([self.global_query] if torch.is_tensor(self.global_query) else []))
+        return self.xyz_layers[0]
 
     def _sampling_chain(self, side):
         """FPS level after level (each level samples the previous level's samples)."""
