@@ -365,12 +365,15 @@ def eval_main(args, rank, world, dev, pinned_cpus):
     pred, _ = model(batches[0][0], is_training=True)            # creates the variables; one training step moves the statistics
     model.loss(pred, batches[0][1], batches[0][2]).backward()
     step_no = [0]
+    torch.cuda.synchronize()
+    ready = torch.cuda.Event()          # the batches are resident: a forward's plan waits for this only, not for the previous forward
+    ready.record()
 
     def one_step():
         p_ = batches[step_no[0] % NUM_BATCHES][0]
         step_no[0] += 1
         with torch.no_grad():
-            return model(p_, is_training=False)[0]
+            return model(p_, is_training=False, points_ready=ready)[0]
 
     for _ in range(PRIME_STEPS):
         one_step()
