@@ -360,6 +360,7 @@ def eval_main(args, rank, world, dev, pinned_cpus):
     """forward-only secondary line of the headline workload: graph construction + inference forward of the S3DIS net on 16
     resident blocks per GPU, batch-norm moving statistics, every separable layer as one kernel"""
     from sph3d_gcn_amd import sph3gcn_util as s3g_util
+    s3dis_net.SAMPLING_STREAMS = args.sampling_streams or 2
     batches = [make_batch(rank, dev, w) for w in range(NUM_BATCHES)]
     model = s3dis_net.SPH3DS3DIS(s3dis_net.s3dis_config(NUM_POINT), device=dev)
     pred, _ = model(batches[0][0], is_training=True)            # creates the variables; one training step moves the statistics
@@ -407,6 +408,7 @@ def eval_main(args, rank, world, dev, pinned_cpus):
                                       "blocks/GPU, graph build + forward; separable layers as one kernel where that is the faster "
                                       "form (FUSE_SEPARABLE_INFERENCE = %r)" % (BLOCKS_PER_GPU, fuse_mode),
                           "global_batch": world * BLOCKS_PER_GPU, "points_per_block": NUM_POINT, "atan2": args.atan2,
+                          "sampling_streams": s3dis_net.SAMPLING_STREAMS,
                           "parallelism": "dp%d (replicas, no collective)" % world, "cpus_per_rank": pinned_cpus},
                "ms_per_step_layer_by_layer": round(t_unfused * 1e3, 3),
                "families_ms_per_step": families, "kernels": kernels, "roofline": None, "cpu_baseline": None}
@@ -423,6 +425,7 @@ def secondary_main(args, rank, world, dev, pinned_cpus):
     from sph3d_gcn_amd.harness import modelnet_net, shapenet_net
     name = args.config
     rng = np.random.RandomState(17 + rank)
+    s3dis_net.SAMPLING_STREAMS = args.sampling_streams or (2 if name == "scannet" else 1)
     if name == "modelnet":
         per_gpu, npts = 32, 10000
         cfg = modelnet_net.modelnet_config(npts)
@@ -521,6 +524,7 @@ def secondary_main(args, rank, world, dev, pinned_cpus):
                           "parallelism": "dp%d (one cloud shard per GPU; flat gradient all-reduced over RCCL in %d buckets)"
                                          % (world, len(flat.buckets)),
                           "resident_batches": NUM_BATCHES, "params": flat.num_parameters, "launch_mode": "eager",
+                          "sampling_streams": s3dis_net.SAMPLING_STREAMS,
                           "atan2": args.atan2, "conv_forward": args.conv,
                           "world_size": dist.get_world_size() if dist.is_initialized() else 1,
                           "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
@@ -547,6 +551,9 @@ def main():
     ap.add_argument("--config", choices=("s3dis", "modelnet", "shapenet", "scannet"), default="s3dis",
                     help="workload: 's3dis' = the headline (BASELINE.json's metric); the others are SECONDARY lines for BASELINE "
                          "configs 2, 3 and 5 with the same JSON contract (per-GPU batch 32 / 64 / 1, weak scaling)")
+    ap.add_argument("--sampling-streams", type=int, default=0,
+                    help="HIP streams the plans' sampling chains rotate over (0 = the line's default: 1 for the training lines "
+                         "whose step outweighs its sampling chain, 2 for --eval and scannet, where the chain is what a step waits for)")
     ap.add_argument("--eval", action="store_true",
                     help="SECONDARY line: forward only (is_training=False under no_grad: every separable layer is ONE kernel, "
                          "csrc/sepconv.hip) on the headline's batch; metric 'point-cloud blocks/sec (inference)'")
@@ -581,6 +588,7 @@ def main():
         _PTS_READY[bt[0].data_ptr()] = ev
     pts, label, inner = batches[0]
     step_no = [0]
+    s3dis_net.SAMPLING_STREAMS = args.sampling_streams or 1
     model = s3dis_net.SPH3DS3DIS(s3dis_net.s3dis_config(NUM_POINT), device=dev)
     # variables are created by the first forward (TF-style scopes): one untimed pass, then flat buffers + Adam
     graphs = s3dis_net.build_graphs(pts, model.config)
@@ -751,7 +759,7 @@ def main():
                        "bin_ids": ("bit-identical to the reference build (same ocml atan2f; tests/test_gpu_round3.py)" if args.atan2 == "ocml"
                                    else "shared correctly-rounded atan2f: == CPU oracle, differs from the reference build within an "
                                         "ulp of a bin boundary (0.07 % of level-0 slots)"),
-                       "conv_forward": args.conv,
+                       "conv_forward": args.conv, "sampling_streams": s3dis_net.SAMPLING_STREAMS,
                        "world_size": dist.get_world_size() if dist.is_initialized() else 1,
                        "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "rccl_version": _rccl_version(), "cpus_per_rank": pinned_cpus},

@@ -85,6 +85,11 @@ def _separable_conv3d_block(net, list_channels, bin_size, nn_index, nn_count, fi
 
 
 _side_stream = {}
+# sampling streams the plans rotate over (set before the first plan of a device).  1: every plan's sampling chain runs behind the
+# previous one's — right when a step has more feature-path work than sampling (the S3DIS training step: 9 ms vs 3 ms; with 2
+# the chains of consecutive steps overlap and take CUs from the feature path: 1763 vs 1787 blocks/s).  More when the chain is
+# what a step waits for: the forward-only loop (2: 3.51 -> 3.33 ms) and the 65 536-point plan (2: 53.4 -> 29.7 ms).
+SAMPLING_STREAMS = 1
 
 
 class GraphPlan:
@@ -133,9 +138,14 @@ class GraphPlan:
                 # (stream priorities were measured, round 2: side streams at the lowest and the feature path at the highest
                 # priority change nothing — 11.66 vs 11.68 ms per step; queue priority does not stop resident workgroups
                 # of the three streams from sharing the CUs)
-                streams = _side_stream[xyz.device] = (torch.cuda.Stream(device=xyz.device),
-                                                      torch.cuda.Stream(device=xyz.device))
-            s_fps, s_graph = streams
+                streams = _side_stream[xyz.device] = ([torch.cuda.Stream(device=xyz.device) for _ in range(SAMPLING_STREAMS)],
+                                                      torch.cuda.Stream(device=xyz.device), [0])
+            # the sampling chain is a few thousand strictly sequential rounds on 16 CUs: consecutive plans (whose inputs are
+            # ready) take alternate sampling streams, so that the chain of the next batch runs beside this one's instead of behind
+            # it — what bounds a forward-only loop (3.2 ms of sampling per 3.5-ms forward) and the 65 536-point plan
+            s_fps = streams[0][streams[2][0] % len(streams[0])]
+            streams[2][0] += 1
+            s_graph = streams[1]
             # (Measured round 2, A/B in one gpurun call: the level-0 search kernel — one 1024-thread, 112-KB-LDS workgroup
             # per CU — cannot share a CU with a resident FPS workgroup (16 + 16 waves at 72 VGPRs), so beside the FPS chain
             # its last 16 workgroups run as a second round: 1.15 ms instead of 0.62 (tools/exp_graph_fps.py).  Running the
