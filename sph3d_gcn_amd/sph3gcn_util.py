@@ -75,19 +75,45 @@ class VariableStore(torch.nn.Module):
 
     def collect_losses(self):
         """Sum of the 'losses' collection entries created by weight_decay (utils/sph3gcn_util.py:82-84)."""
-        total = None
-        for name, coef in self._decay:
-            term = 0.5 * self.params[self._key(name)].pow(2).sum() * coef
-            total = term if total is None else total + term
-        return total
+        if not self._decay:
+            return None
+        return l2_sum([self.params[self._key(name)] for name, _c in self._decay], [c for _n, c in self._decay])
 
     def regularization_loss(self):
         """tf.losses.get_regularization_loss(): sum of l2_loss over BN beta/gamma (:330-331)."""
-        total = None
-        for name in self._reg:
-            term = 0.5 * self.params[self._key(name)].pow(2).sum()
-            total = term if total is None else total + term
-        return total
+        if not self._reg:
+            return None
+        return l2_sum([self.params[self._key(name)] for name in self._reg], [1.0] * len(self._reg))
+
+
+# sum_i coef_i * tf.nn.l2_loss(p_i) over a list of parameters as a handful of multi-tensor kernels instead of five launches per
+# parameter and as many in the backward pass (the ModelNet step: ~200 launches of 2-5 us on the stream that carries the
+# feature path).  ||p||^2 comes from the multi-tensor 2-norm: within an ulp or two of sum(p * p).
+_coef_cache = {}
+
+
+def l2_sum(params, coefs):
+    """sum_i coefs[i] * 0.5 * sum(params[i] ** 2), differentiable in the parameters"""
+    key = (tuple(float(c) for c in coefs), params[0].device)
+    c = _coef_cache.get(key)
+    if c is None:
+        c = _coef_cache[key] = torch.tensor(key[0], dtype=torch.float32, device=params[0].device)
+    return _L2SumList.apply(c, key[0], *params)
+
+
+class _L2SumList(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, coef_t, coef_list, *params):
+        ctx.coef_list = list(coef_list)
+        ctx.save_for_backward(*params)
+        sq = torch.stack(torch._foreach_norm([p.detach() for p in params])).square()      # ||p_i||^2
+        return 0.5 * (sq * coef_t).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = torch._foreach_mul(list(ctx.saved_tensors), ctx.coef_list)                 # coef_i * p_i: one multi-tensor launch
+        grads = torch._foreach_mul(grads, g)
+        return (None, None) + tuple(grads)
 
 
 _default_store = VariableStore()
