@@ -407,6 +407,16 @@ int sph3d_depthwise_conv3d_grad_t_cat(int B, int N, int M, int F, int Ca, int Cb
 int sph3d_adam_step(long long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                     float beta2, float eps, int step, sph3d_stream_t stream);
 
+/* the segmentation nets' training loss (models/SPH3D_s3dis.py:116-133: per block the mean over the points with inner_label > 0
+ * of the sparse softmax cross-entropy, summed over the batch by the caller) and its gradient in one launch:
+ *   loss_part[b * S + s], S = sph3d_masked_softmax_xent_parts(N): the shares of S slices of block b's points in
+ *       loss_b = mean_{n: inner > 0} ( logsumexp(logits[b,n,:]) - logits[b,n,label[b,n]] )      (0 for a block without such points)
+ *   dlogits[b,n,:] = d(sum_b loss_b) / d logits[b,n,:]
+ * logits [B,N,C] fp32, label [B,N] int64, inner_label [B,N] fp32; deterministic (fixed-order reductions). */
+int sph3d_masked_softmax_xent_parts(int N);
+int sph3d_masked_softmax_xent(int B, int N, int C, const float* logits, const long long* label, const float* inner_label,
+                              float* loss_part, float* dlogits, sph3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,8 @@ SIGNATURES = {
     "sph3d_pointwise_gemm_bnstats_blocks": (_I, [_I] * 3),
     "sph3d_pointwise_gemm_bnstats": (_I, [_I] * 3 + [_P] * 6),
     "sph3d_nngrid_launches": (ctypes.c_longlong, []),
+    "sph3d_masked_softmax_xent_parts": (_I, [_I]),
+    "sph3d_masked_softmax_xent": (_I, [_I, _I, _I] + [_P] * 5 + [_P]),
     "sph3d_adam_step": (_I, [ctypes.c_longlong] + [_P] * 4 + [_F] * 4 + [_I, _P]),
     "sph3d_pointwise_gemm_skinny_supported": (_I, [_I] * 4),
     "sph3d_pointwise_gemm_skinny": (_I, [_I] * 4 + [_P] * 6),
@@ -139,7 +141,7 @@ def timing_stop():
     return out
 
 
-_NO_TIME = ("sph3d_abi_version", "sph3d_last_error", "sph3d_build_info", "workspace", "_blocks", "_supported", "_sizes", "_ucap", "_launches")
+_NO_TIME = ("sph3d_abi_version", "sph3d_last_error", "sph3d_build_info", "workspace", "_blocks", "_supported", "_sizes", "_ucap", "_launches", "_parts")
 
 
 class _Proxy:

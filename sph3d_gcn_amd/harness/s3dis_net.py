@@ -456,9 +456,36 @@ class _EndPoints(dict):
         raise KeyError(key)
 
 
+class _MaskedXentFn(torch.autograd.Function):
+    """the loss below as one kernel that also produces the gradient with respect to the logits (include/sph3d.h:
+    sph3d_masked_softmax_xent): -> [B, S], a block's loss in S shares"""
+
+    @staticmethod
+    def forward(ctx, pred, label, inner_label):
+        from .. import _lib
+        B, N, C = pred.shape
+        pred = _lib.f32(pred)
+        label = label.reshape(B, N).long().contiguous()
+        inner = inner_label.reshape(B, N).float().contiguous()
+        S = _lib.lib().sph3d_masked_softmax_xent_parts(N)
+        loss_part = torch.empty((B, S), dtype=torch.float32, device=pred.device)       # a block's loss in S slices of its points
+        dlogits = torch.empty_like(pred)
+        _lib.check(_lib.lib().sph3d_masked_softmax_xent(B, N, C, _lib.ptr(pred), _lib.ptr(label), _lib.ptr(inner),
+                                                        _lib.ptr(loss_part), _lib.ptr(dlogits), _lib.stream_ptr()))
+        ctx.save_for_backward(dlogits)
+        return loss_part
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g[:, 0].reshape(-1, 1, 1), None, None       # (the slices of a block share its upstream gradient)
+
+
 def get_loss(pred, label, end_points, inner_label):
     """models/SPH3D_s3dis.py:116-133: sum over the batch of the mean cross-entropy over inner points."""
     B, N, C = pred.shape
+    if pred.is_cuda:
+        return _MaskedXentFn.apply(pred, label, inner_label).sum()
     loss = F.cross_entropy(pred.reshape(-1, C), label.reshape(-1), reduction='none').reshape(B, N)
     mask = (inner_label > 0).to(loss.dtype)
     cnt = mask.sum(dim=1)
