@@ -152,8 +152,11 @@ class _Proxy:
         self._cache = {}
 
     def __getattr__(self, name):
+        # (reached once per symbol: the result is stored on the instance, so later look-ups never come here — 180 look-ups per
+        # step at 2 us each otherwise)
         fn = getattr(self._cdll, name)     # AttributeError if not exported
         if any(k in name for k in _NO_TIME):
+            self.__dict__[name] = fn
             return fn
         w = self._cache.get(name)
         if w is None:
@@ -173,6 +176,7 @@ class _Proxy:
                 _timing.append((_name, tuple(args[i] for i in _pos if i < len(args)), e0, e1))
                 return rc
             self._cache[name] = w
+        self.__dict__[name] = w
         return w
 
 
