@@ -588,7 +588,7 @@ static int nn_stats_tile(int M, int N, int Kd, int& bm, int& bn)
     if (!whole) return 0;
     auto ntiles = [&](int a, int b) { return (long long)((M + a - 1) / a) * ((N + b - 1) / b); };
     if (N > 64 && ntiles(128, 128) >= 512) { bm = 128; bn = 128; }
-    else if (N <= 64 && ntiles(128, 64) >= 512) { bm = 128; bn = 64; }
+    else if (ntiles(128, 64) >= 512) { bm = 128; bn = 64; }      // (N > 64 too: 32768 x 1024 -> 128 measured 81 vs 90 us with 64 x 64)
     else { bm = 64; bn = 64; }
     return 2 * (M / bm);
 }
