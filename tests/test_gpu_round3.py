@@ -860,3 +860,35 @@ def test_masked_softmax_cross_entropy_kernel_equals_the_framework_formula(dev):
         assert abs(float(loss.detach()) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
         assert float((grad.double() - gref).abs().max()) <= 2e-6 * max(1e-3, float(gref.abs().max()))
         assert float(grad[0].abs().max()) == 0.0
+
+
+def test_plans_on_rotating_sampling_streams_give_the_same_forward(dev):
+    """harness: with SAMPLING_STREAMS = 2 and a ready event, the plans of consecutive forwards are built side by side on two
+    sampling streams (the forward-only bench line): logits identical to the one-stream order, batch after batch"""
+    import torch
+    from sph3d_gcn_amd.harness import s3dis_net, synth
+    cfg = s3dis_net.small_config(2048)
+    batches = []
+    for i in range(3):
+        xyz, _label, _inner = synth.s3dis_batch(40 + i, 2, 2048, extent=(1.0, 1.0, 1.5))
+        batches.append(torch.from_numpy(xyz).to(dev))
+    model = s3dis_net.SPH3DS3DIS(cfg, device=dev, seed=3)
+    with torch.no_grad():
+        model(batches[0], is_training=True)                       # creates the variables (and moves the statistics once)
+        torch.cuda.synchronize()
+        ready = torch.cuda.Event()
+        ready.record()
+        want = [model(b, is_training=False, points_ready=ready)[0].clone() for b in batches]
+        torch.cuda.synchronize()
+        old = s3dis_net.SAMPLING_STREAMS
+        s3dis_net._side_stream.clear()
+        s3dis_net.SAMPLING_STREAMS = 2
+        try:
+            for _rep in range(3):
+                got = [model(b, is_training=False, points_ready=ready)[0] for b in batches]      # three plans in flight
+                torch.cuda.synchronize()
+                for g, w in zip(got, want):
+                    assert torch.equal(g, w)
+        finally:
+            s3dis_net._side_stream.clear()
+            s3dis_net.SAMPLING_STREAMS = old
