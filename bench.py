@@ -525,7 +525,7 @@ def secondary_main(args, rank, world, dev, pinned_cpus):
                                          % (world, len(flat.buckets)),
                           "resident_batches": NUM_BATCHES, "params": flat.num_parameters, "launch_mode": "eager",
                           "sampling_streams": s3dis_net.SAMPLING_STREAMS,
-                          "atan2": args.atan2, "conv_forward": args.conv,
+                          "atan2": args.atan2,
                           "world_size": dist.get_world_size() if dist.is_initialized() else 1,
                           "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                           "cpus_per_rank": pinned_cpus},
@@ -557,8 +557,6 @@ def main():
     ap.add_argument("--eval", action="store_true",
                     help="SECONDARY line: forward only (is_training=False under no_grad: every separable layer is ONE kernel, "
                          "csrc/sepconv.hip) on the headline's batch; metric 'point-cloud blocks/sec (inference)'")
-    ap.add_argument("--conv", choices=("gather", "lds"), default="gather",
-                    help="depthwise forward kernel: 'gather' (conv3d.hip) or 'lds' (convlds.hip: LDS tiles + per-graph plan)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -572,9 +570,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     pinned_cpus = hdist.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     _lib.lib()
-    from sph3d_gcn_amd import tf_buildkernel, _plan
+    from sph3d_gcn_amd import tf_buildkernel
     tf_buildkernel.set_atan2(args.atan2)          # reaches the fused graph kernel too (tf_nnquery.build_sphere_graph)
-    _plan.set_mode(args.conv)
     if args.config != "s3dis":
         return secondary_main(args, rank, world, dev, pinned_cpus)
     if args.eval:
@@ -720,17 +717,6 @@ def main():
             if iso:
                 conv_gather["isolated_us"] = round(iso * 1e6, 1)
                 conv_gather["isolated_frac"] = round(ab / 1e9 / iso / HBM_PEAK_GBS, 4)
-            from sph3d_gcn_amd import _plan
-            prev_mode = _plan.get_mode()
-            _plan.set_mode("lds")                # the LDS-tile kernel of the same layer (csrc/convlds.hip; opt-in: its per-graph
-            try:                                 # plan costs more graph-stream time than it saves on the feature path)
-                iso_t = isolated_call_seconds(name, ints, dev)
-            finally:
-                _plan.set_mode(prev_mode)
-                _plan.clear()
-            if iso_t:
-                conv_gather["lds_kernel_isolated_us"] = round(iso_t * 1e6, 1)
-                conv_gather["lds_kernel_isolated_frac"] = round(ab / 1e9 / iso_t / HBM_PEAK_GBS, 4)
     sph3d_ms = sum(v[0] for v in per.values()) / ev_steps
 
     if is_rank0:
@@ -759,7 +745,7 @@ def main():
                        "bin_ids": ("bit-identical to the reference build (same ocml atan2f; tests/test_gpu_round3.py)" if args.atan2 == "ocml"
                                    else "shared correctly-rounded atan2f: == CPU oracle, differs from the reference build within an "
                                         "ulp of a bin boundary (0.07 % of level-0 slots)"),
-                       "conv_forward": args.conv, "sampling_streams": s3dis_net.SAMPLING_STREAMS,
+                       "sampling_streams": s3dis_net.SAMPLING_STREAMS,
                        "world_size": dist.get_world_size() if dist.is_initialized() else 1,
                        "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "rccl_version": _rccl_version(), "cpus_per_rank": pinned_cpus},

@@ -60,9 +60,16 @@ const char* sph3d_build_info(void);          /* "gfx950 hipcc <ver> ..." */
  * every query is independent (csrc/nngrid.hip): the early positions — radius <= 3 * radius, the queries that would otherwise
  * scan the whole cloud for a handful of hits — are searched over a cell grid, the late ones by an early-stopping scan per
  * query.  Whenever some query does need the growth (device-side flag, no host round trip) the chain walk over the cloud
- * (csrc/nnquery.hip) computes the call.  Same rows bit for bit either way.  The grid lives in a library-owned per-stream device buffer
- * (hipMalloc on first use, kept; the reference signature has no workspace).  Environment SPH3D_NNGRID=0 (read once) turns
- * the grid off. */
+ * (csrc/nnquery.hip) computes the call.  Same rows bit for bit either way.
+ * Where the grid lives: the entry points WITH the reference launcher's signature (no workspace argument:
+ * sph3d_build_sphere_neighbor[_fixed], sph3d_build_sphere_graph[_ocml]) are conveniences that keep one library-owned
+ * device buffer per (device, stream) — hipMalloc on first use, hipFree (a device-wide wait) when it has to grow; a stream
+ * that is being captured gets no buffer (no grid: the chain kernel alone).  The `_ws` twins below take the grid's memory
+ * from the caller (sph3d_build_sphere_neighbor_workspace bytes, 16-byte aligned): they never allocate, never synchronise and
+ * hold no state between calls — what SURVEY 8b asks of every kernel entry; the Python ops of this package call only those.
+ * workspace == NULL there: no grid.  sph3d_release_stream_scratch(stream) frees the convenience buffer of `stream` on the
+ * current device (call it before destroying the stream), sph3d_release_all_scratch() every buffer of the current device;
+ * both return the number of buffers freed.  Environment SPH3D_NNGRID=0 (read once) turns the grid off. */
 #define SPH3D_MAX_GROWTH_PASSES 4096
 /* diagnostic: calls so far in this process whose early positions went through the cell grid */
 long long sph3d_nngrid_launches(void);
@@ -78,6 +85,20 @@ int sph3d_build_sphere_neighbor_fixed(int B, int N, int M, int nn_sample, float 
                                 const float* database, const float* query,
                                 int* nn_index, int* nn_count, float* nn_dist,
                                 sph3d_stream_t stream);
+
+/* The same two searches with the cell grid's memory from the caller (see above; tf_nnquery.cpp:53-54: the op's Compute
+ * allocates every buffer the launcher touches — this is that contract). */
+size_t sph3d_build_sphere_neighbor_workspace(int B, int N, int M);
+int sph3d_build_sphere_neighbor_ws(int B, int N, int M, int nn_sample, float radius,
+                                   const float* database, const float* query,
+                                   int* nn_index, int* nn_count, float* nn_dist,
+                                   void* workspace, size_t workspace_bytes, sph3d_stream_t stream);
+int sph3d_build_sphere_neighbor_fixed_ws(int B, int N, int M, int nn_sample, float radius,
+                                   const float* database, const float* query,
+                                   int* nn_index, int* nn_count, float* nn_dist,
+                                   void* workspace, size_t workspace_bytes, sph3d_stream_t stream);
+int sph3d_release_stream_scratch(sph3d_stream_t stream);
+int sph3d_release_all_scratch(void);
 
 /* replaces buildCubeNeighborLauncher (tf_nnquery_gpu.cu:123-127; kernel
  * cal_nn_binidx_cube :72-113; op BuildCubeNeighbor tf_nnquery.cpp:116-168).
@@ -103,6 +124,14 @@ int sph3d_build_sphere_graph_ocml(int B, int N, int M, int nn_sample, float radi
                              const float* database, const float* query,
                              int* nn_index, int* nn_count, float* nn_dist, int* filt_index,
                              void* transpose_workspace, size_t transpose_workspace_bytes, sph3d_stream_t stream);
+
+/* Both of the above with the search's cell grid from the caller (search_workspace: sph3d_build_sphere_neighbor_workspace(B, N, M)
+ * bytes, NULL = no grid): no allocation, legal under stream capture.  ocml: 0 = sph3d_build_sphere_graph, 1 = ..._ocml. */
+int sph3d_build_sphere_graph_ws(int B, int N, int M, int nn_sample, float radius, int n, int p, int q, int ocml,
+                                const float* database, const float* query,
+                                int* nn_index, int* nn_count, float* nn_dist, int* filt_index,
+                                void* transpose_workspace, size_t transpose_workspace_bytes,
+                                void* search_workspace, size_t search_workspace_bytes, sph3d_stream_t stream);
 
 /* ---- buildkernel --------------------------------------------------------
  * replaces sphericalKernelLauncher (tf_ops/buildkernel/tf_buildkernel_gpu.cu:83-89;
@@ -271,40 +300,10 @@ int sph3d_farthest_point_sample(int b, int n, int m, const float* inp, int* out,
 int sph3d_gather_nd(int B, int N, long long S, int row, const int* pairs, const void* params, void* out,
                     sph3d_stream_t stream);
 
-/* ---- depthwise convolution gathered from LDS tiles (csrc/convlds.hip) -------------------------------
- * Same results, bit for bit, as sph3d_depthwise_conv3d (replaces depthwise_conv3d_forward,
- * tf_ops/convolution/tf_conv3d_gpu.cu:7-29): the neighbour rows of a tile of <= 32 spatially consecutive output
- * points are staged in LDS once (LDS-DMA) and every edge is one LDS read instead of one L2 -> L1 row gather.
- * A per-graph PLAN (shared by every convolution and channel slice on the graph), all device arrays from the caller:
- *   sph3d_spatial_order   order[B,N]: a permutation of each cloud in which consecutive points are close (Morton
- *                         cells); any permutation (or NULL = index order) is valid, a random one only loses row reuse;
- *   sph3d_conv_plan       nn_index / nn_count / bin_index [B,M,K] of the graph (K <= 64, N <= 65536 source rows,
- *                         F <= 65 bins; out-of-range ids / bins are clamped like the gather kernels do).  Per chunk of
- *                         64 consecutive positions of `order` (c = b*ceil(M/64) + chunk):
- *                           chunk_hdr[c*132]        tiles of the chunk; per tile t: [1+2t] = first | targets << 8 | rows << 16,
- *                                                   [2+2t] = offset of its row list in the chunk's slab
- *                           records[(c*64 + p)*32]  per target 64 u16 entries in neighbour order:
- *                                                   LDS slot of the edge's row | bin << 8 (padding: zero row, zero filter row);
- *                                                   a tile's targets are contiguous from `first`, most neighbours first
- *                           target_meta[c*64 + p]   target id | neighbour count << 24
- *                           row_lists[c*4096 ...]   the tiles' source-row ids (u16), ascending per tile
- *                         sizes from sph3d_conv_plan_sizes; sph3d_conv_plan_ucap(F) = rows a tile stages (0: F unsupported).
- * The kernel covers r in {1,2}, C a multiple of 64 (64-channel slices: 256-B rows), K <= 64; _cat reads the channel
- * concatenation [input_a (Ca) | input_b (Cb)] in place (Ca, Cb multiples of 64). */
+/* A permutation of each cloud in which consecutive points are close in space (counting sort by the Morton code of a point's
+ * cell in a grid over the cloud's bounding box): order[B,N] int32.  A processing order for gather kernels — it never changes a
+ * result, only which rows a workgroup touches together. */
 int sph3d_spatial_order(int B, int N, const float* xyz, int* order, sph3d_stream_t stream);
-int sph3d_conv_plan_ucap(int F);
-int sph3d_conv_plan_sizes(int B, int M, size_t* hdr_ints, size_t* rec_words, size_t* meta_ints, size_t* rowlist_shorts);
-int sph3d_conv_plan(int B, int N, int M, int K, int F, const int* order, const int* nn_index, const int* nn_count,
-                    const int* bin_index, int* chunk_hdr, unsigned* records, int* target_meta,
-                    unsigned short* row_lists, sph3d_stream_t stream);
-int sph3d_depthwise_conv3d_lds_supported(int F, int C, int r, int K);   /* 1 if the LDS kernel applies */
-int sph3d_depthwise_conv3d_lds(int B, int N, int M, int F, int C, int r, const int* chunk_hdr, const unsigned* records,
-                               const int* target_meta, const unsigned short* row_lists, const float* input,
-                               const float* filter, float* output, sph3d_stream_t stream);
-int sph3d_depthwise_conv3d_lds_cat(int B, int N, int M, int F, int Ca, int Cb, int r, const int* chunk_hdr,
-                                   const unsigned* records, const int* target_meta, const unsigned short* row_lists,
-                                   const float* input_a, const float* input_b, const float* filter, float* output,
-                                   sph3d_stream_t stream);
 
 /* ---- pointwise 1x1 feature GEMM (fp32 MFMA) -----------------------------
  * replaces the tf.matmul inside separable_conv3d / pointwise_conv3d /
@@ -412,7 +411,9 @@ int sph3d_adam_step(long long n, float* param, const float* grad, float* exp_avg
  *   loss_part[b * S + s], S = sph3d_masked_softmax_xent_parts(N): the shares of S slices of block b's points in
  *       loss_b = mean_{n: inner > 0} ( logsumexp(logits[b,n,:]) - logits[b,n,label[b,n]] )      (0 for a block without such points)
  *   dlogits[b,n,:] = d(sum_b loss_b) / d logits[b,n,:]
- * logits [B,N,C] fp32, label [B,N] int64, inner_label [B,N] fp32; deterministic (fixed-order reductions). */
+ * logits [B,N,C] fp32, label [B,N] int64, inner_label [B,N] fp32; deterministic (fixed-order reductions).
+ * dlogits == NULL: the losses only (evaluation: no gradient pass, no [B,N,C] store).  An inner point whose label lies
+ * outside [0, C) makes its block's loss and its gradient row NaN (the reference's GPU op yields NaN there as well). */
 int sph3d_masked_softmax_xent_parts(int N);
 int sph3d_masked_softmax_xent(int B, int N, int C, const float* logits, const long long* label, const float* inner_label,
                               float* loss_part, float* dlogits, sph3d_stream_t stream);

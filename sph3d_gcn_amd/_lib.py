@@ -26,6 +26,12 @@ SIGNATURES = {
     "sph3d_build_info": (ctypes.c_char_p, []),
     "sph3d_build_sphere_neighbor": (_I, [_I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "sph3d_build_sphere_neighbor_fixed": (_I, [_I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
+    "sph3d_build_sphere_neighbor_workspace": (_S, [_I, _I, _I]),
+    "sph3d_build_sphere_neighbor_ws": (_I, [_I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _S, _P]),
+    "sph3d_build_sphere_neighbor_fixed_ws": (_I, [_I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _S, _P]),
+    "sph3d_release_stream_scratch": (_I, [_P]),
+    "sph3d_release_all_scratch": (_I, []),
+    "sph3d_build_sphere_graph_ws": (_I, [_I, _I, _I, _I, _F, _I, _I, _I, _I] + [_P] * 6 + [_P, _S, _P, _S, _P]),
     "sph3d_build_cube_neighbor": (_I, [_I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P]),
     "sph3d_spherical_kernel": (_I, [_I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
     "sph3d_spherical_kernel_ocml": (_I, [_I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
@@ -51,12 +57,6 @@ SIGNATURES = {
     "sph3d_depthwise_conv3d_cat": (_I, [_I] * 8 + [_P] * 8),
     "sph3d_depthwise_conv3d_grad_t_cat": (_I, [_I] * 7 + [_P] * 12 + [_P, _S, _P]),
     "sph3d_spatial_order": (_I, [_I, _I, _P, _P, _P]),
-    "sph3d_conv_plan_ucap": (_I, [_I]),
-    "sph3d_conv_plan_sizes": (_I, [_I, _I] + [_P] * 4),
-    "sph3d_conv_plan": (_I, [_I] * 5 + [_P] * 9),
-    "sph3d_depthwise_conv3d_lds_supported": (_I, [_I] * 4),
-    "sph3d_depthwise_conv3d_lds": (_I, [_I] * 6 + [_P] * 8),
-    "sph3d_depthwise_conv3d_lds_cat": (_I, [_I] * 7 + [_P] * 9),
     "sph3d_scatter_grad_t": (_I, [_I] * 4 + [_P] * 6),
     "sph3d_scatter_grad_workspace": (_S, [_I] * 4),
     "sph3d_mean_interpolate": (_I, [_I] * 5 + [_P] * 5),
@@ -141,7 +141,7 @@ def timing_stop():
     return out
 
 
-_NO_TIME = ("sph3d_abi_version", "sph3d_last_error", "sph3d_build_info", "workspace", "_blocks", "_supported", "_sizes", "_ucap", "_launches", "_parts")
+_NO_TIME = ("sph3d_abi_version", "sph3d_last_error", "sph3d_build_info", "workspace", "_release_", "_blocks", "_supported", "_launches", "_parts")
 
 
 class _Proxy:

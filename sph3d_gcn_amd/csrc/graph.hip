@@ -174,9 +174,122 @@ __global__ __launch_bounds__(256) void tg_fill(int B, int N, int M, int K, int F
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// spatial order: counting sort of a cloud's points by the Morton code of their cell in a 2^bpa-per-axis grid over the
+// bounding box (cells isotropic, sized by the longest axis).  One 1024-thread workgroup per cloud, histogram in LDS.
+// Order inside a cell = arrival order of an LDS atomic: it only decides which targets share a tile, never a result.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned spread3(unsigned v)      // 10 bits -> every third bit
+{
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__global__ __launch_bounds__(1024) void spatial_order_kernel(int N, int bpa, const float* __restrict__ xyz,
+                                                              int* __restrict__ order)
+{
+    extern __shared__ int hist[];                  // [1 << 3*bpa]
+    __shared__ float red[6][16];
+    __shared__ int wsum[16];
+    const int b = (int)blockIdx.x;
+    const int tid = (int)threadIdx.x;
+    const int NB = 1 << (3 * bpa);
+    const float* p = xyz + (size_t)b * N * 3;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int n = tid; n < N; n += 1024)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float v = p[n * 3 + a];
+            lo[a] = fminf(lo[a], v);
+            hi[a] = fmaxf(hi[a], v);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], o));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o));
+        }
+    if ((tid & 63) == 0)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            red[a][tid >> 6] = lo[a];
+            red[3 + a][tid >> 6] = hi[a];
+        }
+    for (int i = tid; i < NB; i += 1024) hist[i] = 0;
+    __syncthreads();
+    float ext = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float l = red[a][0], h = red[3 + a][0];
+        for (int w = 1; w < 16; w++) {
+            l = fminf(l, red[a][w]);
+            h = fmaxf(h, red[3 + a][w]);
+        }
+        lo[a] = l;
+        ext = fmaxf(ext, h - l);
+    }
+    const int G = 1 << bpa;
+    const float inv = ext > 0.f ? (float)G / ext : 0.f;
+    auto key_of = [&](int n) {
+        unsigned k = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            int q = (int)((p[n * 3 + a] - lo[a]) * inv);
+            q = q < 0 ? 0 : (q > G - 1 ? G - 1 : q);
+            k |= spread3((unsigned)q) << a;
+        }
+        return (int)k;
+    };
+    for (int n = tid; n < N; n += 1024) atomicAdd(&hist[key_of(n)], 1);
+    __syncthreads();
+    // exclusive scan of the histogram: each thread owns NB/1024 consecutive buckets (NB >= 1024 by construction)
+    const int per = NB >> 10;
+    int s = 0;
+    for (int j = 0; j < per; j++) s += hist[tid * per + j];
+    int incl = s;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if ((tid & 63) >= o) incl += t;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (tid >> 6); w++) base += wsum[w];
+    int run = base + incl - s;
+    for (int j = 0; j < per; j++) {
+        const int c = hist[tid * per + j];
+        hist[tid * per + j] = run;
+        run += c;
+    }
+    __syncthreads();
+    for (int n = tid; n < N; n += 1024) order[(size_t)b * N + atomicAdd(&hist[key_of(n)], 1)] = n;
+}
+
 }  // namespace sph3d
 
 using namespace sph3d;
+
+extern "C" int sph3d_spatial_order(int B, int N, const float* xyz, int* order, sph3d_stream_t stream)
+{
+    SPH3D_REQUIRE(B >= 0 && N > 0, "spatial_order: bad dims B=%d N=%d", B, N);
+    if (B == 0) return SPH3D_OK;
+    int bpa = 4;                                   // buckets ~ 4 N, between 2^12 and 2^15
+    while (bpa < 5 && (1 << (3 * bpa)) < 4 * N) bpa++;
+    const size_t lds = sizeof(int) * ((size_t)1 << (3 * bpa));
+    int rc = SPH3D_OK;
+    if (lds > 64 * 1024) {
+        rc = check_hip(hipFuncSetAttribute((const void*)spatial_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                       "spatial_order: hipFuncSetAttribute");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(spatial_order_kernel, dim3(B), dim3(1024), lds, as_stream(stream), N, bpa, xyz, order);
+    return check_launch("sph3d_spatial_order");
+}
+
 
 // bytes of scratch the build itself needs (the in-degree / cursor array)
 extern "C" size_t sph3d_graph_transpose_workspace(int B, int N, int M, int K, int F)

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(1024) void masked_xent_kernel(int N, int C, int chu
     float* dg = dlogits + (size_t)b * N * C;
     float sum = 0.f;
     for (int n = n0 + (int)threadIdx.x; n < n1; n += 1024) {
-        float* drow = dg + (size_t)n * C;
+        float* drow = dlogits != nullptr ? dg + (size_t)n * C : nullptr;      // dlogits == NULL: loss only (no gradient wanted)
         if (in[n] > 0.f) {
             const float* row = lg + (size_t)n * C;
             float m = row[0];
@@ -50,11 +50,17 @@ __global__ __launch_bounds__(1024) void masked_xent_kernel(int N, int C, int chu
             float se = 0.f;
             for (int c = 0; c < C; c++) se += expf(row[c] - m);
             long long y = lb[n];
-            y = y < 0 ? 0 : (y >= C ? C - 1 : y);                  // memory safety for labels outside [0, C)
-            sum += (m + logf(se)) - row[y];
-            const float r = inv / se;
-            for (int c = 0; c < C; c++) drow[c] = expf(row[c] - m) * r - (c == (int)y ? inv : 0.f);
-        } else {
+            // a label outside [0, C): the reference's op yields NaN for that row on the GPU (and the CPU path here raises):
+            // the block's loss and the row's gradient are NaN, never a silently clamped class; reads stay in range
+            const bool bad = y < 0 || y >= C;
+            y = bad ? 0 : y;
+            sum += bad ? __builtin_nanf("") : (m + logf(se)) - row[y];
+            if (drow != nullptr) {
+                const float r = inv / se;
+                for (int c = 0; c < C; c++)
+                    drow[c] = bad ? __builtin_nanf("") : expf(row[c] - m) * r - (c == (int)y ? inv : 0.f);
+            }
+        } else if (drow != nullptr) {
             for (int c = 0; c < C; c++) drow[c] = 0.f;
         }
     }

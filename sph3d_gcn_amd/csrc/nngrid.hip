@@ -529,8 +529,23 @@ __global__ __launch_bounds__(256) void nndense_kernel(
 
 static std::atomic<long long> g_grid_launches{0};
 
+// bytes of the cell grid of one call: header + flag, cell starts, the cloud in cell order, the query orders
+size_t nngrid_workspace_bytes(int B, int N, int M)
+{
+    if (B <= 0 || N <= 0 || M <= 0) return 0;
+    // shapes the grid never takes (the same test as nngrid_search, minus what depends on K and the radius mode)
+    if (N < 1024 || N > 65536 || M < 64 || M > kMaxPositions * kRefBlock || (long long)N * M < (1LL << 22)) return 0;
+    const size_t hdrBytes = 1024 + sizeof(GridHdr) * (size_t)B;
+    const size_t csBytes = sizeof(int) * (size_t)B * (kGridMaxCells + 1);
+    const size_t ptBytes = sizeof(float4) * (size_t)B * N;
+    const size_t qoBytes = sizeof(int) * (size_t)B * M;
+    const size_t a16 = 15;
+    return ((hdrBytes + a16) & ~a16) + ((csBytes + a16) & ~a16) + ptBytes + qoBytes;
+}
+
 int nngrid_search(int B, int N, int M, int K, float radius, int fixed, const float* database, const float* query, int* nn_index,
-                  int* nn_count, float* nn_dist, const GraphFuse* fuse, hipStream_t st, const int** gate, int* grid_done)
+                  int* nn_count, float* nn_dist, const GraphFuse* fuse, hipStream_t st, const int** gate, int* grid_done,
+                  void* workspace, size_t workspace_bytes, bool library_scratch)
 {
     // worth it from ~4 M point pairs per cloud (below, the chain kernel's scan of the whole cloud from LDS is as fast as the
     // grid's build + search: 2048 x 512 measured 60 vs 68 us); the sorted hit lists hold 16-bit indices; with more than 32 clouds
@@ -559,7 +574,17 @@ int nngrid_search(int B, int N, int M, int K, float radius, int fixed, const flo
     const size_t qoBytes = sizeof(int) * (size_t)B * M;
     const size_t a16 = 15;
     const size_t total = ((hdrBytes + a16) & ~a16) + ((csBytes + a16) & ~a16) + ptBytes + qoBytes;
-    unsigned char* ws = (unsigned char*)stream_scratch(st, total);
+    // the grid's memory: the caller's workspace (the `_ws` entry points: no allocation, legal under stream capture), or — the
+    // convenience entry points with the reference's signature — the library's buffer of this (device, stream); none: no grid
+    unsigned char* ws = (unsigned char*)workspace;
+    if (ws != nullptr) {
+        if (workspace_bytes < total || (reinterpret_cast<size_t>(ws) & 15) != 0) {
+            set_error("BuildSphereNeighbor: workspace %zu B < required %zu B (or not 16-byte aligned)", workspace_bytes, total);
+            return SPH3D_EWORKSPACE;
+        }
+    } else if (library_scratch) {
+        ws = (unsigned char*)stream_scratch(st, total);
+    }
     if (ws == nullptr) return 0;
     int* flag = (int*)ws;
     GridRadii* radii = (GridRadii*)(ws + 64);

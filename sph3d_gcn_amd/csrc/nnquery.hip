@@ -471,7 +471,8 @@ using namespace sph3d;
 static int sphere_neighbor(int fixed, int B, int N, int M, int nn_sample, float radius,
                            const float* database, const float* query,
                            int* nn_index, int* nn_count, float* nn_dist,
-                           sph3d_stream_t stream, const GraphFuse* fuse = nullptr, bool* fused = nullptr)
+                           sph3d_stream_t stream, const GraphFuse* fuse = nullptr, bool* fused = nullptr,
+                           void* search_ws = nullptr, size_t search_ws_bytes = 0, bool library_scratch = true)
 {
     if (fused) *fused = false;
     SPH3D_REQUIRE(radius > 0, "Range search requires radius>0, got %g", (double)radius);          // tf_nnquery.cpp:60
@@ -502,7 +503,7 @@ static int sphere_neighbor(int fixed, int B, int N, int M, int nn_sample, float 
     static const bool grid_on = !(getenv("SPH3D_NNGRID") && atoi(getenv("SPH3D_NNGRID")) == 0);
     if (grid_on) {
         const int g = nngrid_search(B, N, M, nn_sample, radius, fixed, database, query, nn_index, nn_count, nn_dist, fuse, st, &gate,
-                                    &grid_done);
+                                    &grid_done, search_ws, search_ws_bytes, library_scratch);
         if (g < 0) return g;
         if (g > 0 && fuse != nullptr && fuse->deg != nullptr) {
             const long long cnt = (long long)B * N * fuse->F + fuse->F;
@@ -535,6 +536,29 @@ extern "C" int sph3d_build_sphere_neighbor_fixed(int B, int N, int M, int nn_sam
     return sphere_neighbor(1, B, N, M, nn_sample, radius, database, query, nn_index, nn_count, nn_dist, stream);
 }
 
+// ---- the same searches with the cell grid's memory from the caller: nothing is allocated, so the calls are legal under stream
+// capture and independent of any library state (kernels never allocate).  workspace == NULL: no grid, the chain
+// kernel computes the call (same rows).
+extern "C" size_t sph3d_build_sphere_neighbor_workspace(int B, int N, int M) { return nngrid_workspace_bytes(B, N, M); }
+
+extern "C" int sph3d_build_sphere_neighbor_ws(int B, int N, int M, int nn_sample, float radius,
+                                              const float* database, const float* query,
+                                              int* nn_index, int* nn_count, float* nn_dist,
+                                              void* workspace, size_t workspace_bytes, sph3d_stream_t stream)
+{
+    return sphere_neighbor(0, B, N, M, nn_sample, radius, database, query, nn_index, nn_count, nn_dist, stream, nullptr, nullptr,
+                           workspace, workspace_bytes, false);
+}
+
+extern "C" int sph3d_build_sphere_neighbor_fixed_ws(int B, int N, int M, int nn_sample, float radius,
+                                                    const float* database, const float* query,
+                                                    int* nn_index, int* nn_count, float* nn_dist,
+                                                    void* workspace, size_t workspace_bytes, sph3d_stream_t stream)
+{
+    return sphere_neighbor(1, B, N, M, nn_sample, radius, database, query, nn_index, nn_count, nn_dist, stream, nullptr, nullptr,
+                           workspace, workspace_bytes, false);
+}
+
 // Fused graph construction of one level: neighbour search + spherical-kernel bins (+ the segment counts of
 // the transposed graph) in ONE kernel.  Same outputs, bit for bit, as sph3d_build_sphere_neighbor followed by
 // sph3d_spherical_kernel with the same database / query (and sph3d_graph_transpose's counting pass).
@@ -549,7 +573,8 @@ extern "C" int sph3d_graph_transpose_count(int B, int N, int M, int K, int F, co
 static int build_sphere_graph_impl(bool ocml, int B, int N, int M, int nn_sample, float radius, int n, int p, int q,
                                    const float* database, const float* query,
                                    int* nn_index, int* nn_count, float* nn_dist, int* filt_index,
-                                   void* transpose_workspace, size_t transpose_workspace_bytes, sph3d_stream_t stream)
+                                   void* transpose_workspace, size_t transpose_workspace_bytes, sph3d_stream_t stream,
+                                   void* search_ws = nullptr, size_t search_ws_bytes = 0, bool library_scratch = true)
 {
     // filt_index == NULL: no bins (an inter-level graph: one segment per source point), only the search and the counts
     const bool binned = filt_index != nullptr;
@@ -582,7 +607,8 @@ static int build_sphere_graph_impl(bool ocml, int B, int N, int M, int nn_sample
         if (rc) return rc;
     }
     bool fused = false;
-    int rc = sphere_neighbor(0, B, N, M, nn_sample, radius, database, query, nn_index, nn_count, nn_dist, stream, &fx, &fused);
+    int rc = sphere_neighbor(0, B, N, M, nn_sample, radius, database, query, nn_index, nn_count, nn_dist, stream, &fx, &fused,
+                             search_ws, search_ws_bytes, library_scratch);
     if (rc || fused) return rc;
     // shapes whose hit lists do not fit LDS: the same results from the separate kernels
     if (binned)
@@ -609,6 +635,17 @@ extern "C" int sph3d_build_sphere_graph_ocml(int B, int N, int M, int nn_sample,
 {
     return build_sphere_graph_impl(true, B, N, M, nn_sample, radius, n, p, q, database, query, nn_index, nn_count, nn_dist, filt_index,
                                    transpose_workspace, transpose_workspace_bytes, stream);
+}
+
+extern "C" int sph3d_build_sphere_graph_ws(int B, int N, int M, int nn_sample, float radius, int n, int p, int q, int ocml,
+                                           const float* database, const float* query,
+                                           int* nn_index, int* nn_count, float* nn_dist, int* filt_index,
+                                           void* transpose_workspace, size_t transpose_workspace_bytes,
+                                           void* search_workspace, size_t search_workspace_bytes, sph3d_stream_t stream)
+{
+    return build_sphere_graph_impl(ocml != 0, B, N, M, nn_sample, radius, n, p, q, database, query, nn_index, nn_count, nn_dist,
+                                   filt_index, transpose_workspace, transpose_workspace_bytes, stream, search_workspace,
+                                   search_workspace_bytes, false);
 }
 
 extern "C" int sph3d_build_cube_neighbor(int B, int N, int M, int grid_size, int nn_sample, float length,

@@ -64,11 +64,16 @@ struct GraphFuse {
 // reads non-zero afterwards: a query without a neighbour inside its radius (the reference grows the radius there, and every
 // later position of the chain with it), a grid too coarse to pay, non-finite coordinates.  The chain kernel runs behind it
 // and reads the flag: it starts at position *grid_done, or at 0 when the flag is up.
+// The grid's device memory (nngrid_workspace_bytes) is `workspace` when the caller gave one (too small: SPH3D_EWORKSPACE), else the
+// library's per-(device, stream) buffer when library_scratch is set, else the grid is not used (0).
 int nngrid_search(int B, int N, int M, int K, float radius, int fixed, const float* database, const float* query, int* nn_index,
-                  int* nn_count, float* nn_dist, const GraphFuse* fuse, hipStream_t stream, const int** gate, int* grid_done);
+                  int* nn_count, float* nn_dist, const GraphFuse* fuse, hipStream_t stream, const int** gate, int* grid_done,
+                  void* workspace, size_t workspace_bytes, bool library_scratch);
+size_t nngrid_workspace_bytes(int B, int N, int M);
 
-// api.cpp: a library-owned device buffer of at least `bytes` for work queued on `stream` (one per stream, grown on demand and
-// kept; nullptr if the allocation fails).  Only for state that is dead when the call's last kernel has run.
+// api.cpp: a library-owned device buffer of at least `bytes` for work queued on `stream` of the current device (one per
+// (device, stream), grown on demand and kept; nullptr if the allocation fails or the stream is being captured).  Only for
+// state that is dead when the call's last kernel has run.
 void* stream_scratch(hipStream_t stream, size_t bytes);
 
 }  // namespace sph3d

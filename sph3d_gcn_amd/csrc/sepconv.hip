@@ -404,9 +404,18 @@ __global__ __launch_bounds__(1024) void sepconv_general_kernel(
 }
 
 // shapes of the general kernel: C <= 128 (one, possibly partial, slice) or a multiple of 128; Cout a multiple of 16, <= 512
+// LDS of the general kernel: the depthwise filter slice (F + 1 rows) + the A tile of rbk row blocks
+static size_t sc_general_lds(int F, int C, int r, int rbk)
+{
+    const size_t lpe = C <= 64 ? 16 : 32;
+    return sizeof(float) * ((size_t)(F + 1) * 4 * lpe * r + (size_t)(16 * rbk) * (4 * lpe * r + 4));
+}
+
 static bool sc_general_ok(int N, int F, int C, int r, int K, int Cout)
 {
-    return (r == 1 || r == 2) && C % 4 == 0 && C >= 4 && (C <= 128 || (C % 128 == 0 && C <= 4096)) && Cout % 16 == 0 && Cout >= 16 &&
+    // "supported" is exactly what the launcher can run: the smallest tile (one row block) must fit the CU's LDS next to the
+    // filter slice (F <= 254 alone let kernels with ~95+ bins through, which then failed at launch)
+    return (r == 1 || r == 2) && sc_general_lds(F, C, r, 1) <= 160 * 1024 && C % 4 == 0 && C >= 4 && (C <= 128 || (C % 128 == 0 && C <= 4096)) && Cout % 16 == 0 && Cout >= 16 &&
            Cout <= 512 && F <= 254 && N <= (1 << 24) && K > 0 && (unsigned long long)N * C * 4ull + 1024ull < (1ull << 32);
 }
 
@@ -417,7 +426,8 @@ static int sc_launch_general(int B, int N, int M, int F, int C, int K, int Cout,
 {
     // tile height: as many row blocks as still leave every CU a tile
     const long long pts = (long long)B * M;
-    const int rbk = pts >= 64LL * 512 ? 4 : (pts >= 32LL * 256 ? 2 : 1);
+    int rbk = pts >= 64LL * 512 ? 4 : (pts >= 32LL * 256 ? 2 : 1);
+    while (rbk > 1 && sc_general_lds(F, C, R, rbk) > 160 * 1024) rbk >>= 1;      // many bins: a lower tile beside the larger filter slice
     const size_t lds = sizeof(float) * ((size_t)(F + 1) * 4 * LPE * R + (size_t)(16 * rbk) * (4 * LPE * R + 4));
     SPH3D_REQUIRE(lds <= 160 * 1024, "SeparableConv3dFused: %zu B of LDS needed", lds);
 #define SPH3D_SCG(RB)                                                                                                        \
@@ -438,9 +448,17 @@ static int sc_launch_general(int B, int N, int M, int F, int C, int K, int Cout,
     return check_launch("sph3d_separable_conv3d_fused (general)");
 }
 
+static size_t sc_small_lds(int F, int C, int r)
+{
+    const size_t lpe = C <= 64 ? 16 : 32;
+    const int KT = (C * r + 15) / 16;
+    const int KTP = KT <= 4 ? 4 : (KT <= 8 ? 8 : 16);
+    return sizeof(float) * ((size_t)(F + 1) * 4 * lpe * r + 2 * (size_t)kScTile * (KTP * 16 + 4));
+}
+
 static bool sc_shape_ok(int N, int F, int C, int r, int K, int Cout)
 {
-    return (r == 1 || r == 2) && C % 4 == 0 && C >= 4 && C <= 128 && C * r <= 256 && Cout % 16 == 0 && Cout >= 16 && Cout <= 128 &&
+    return (r == 1 || r == 2) && sc_small_lds(F, C, r) <= 160 * 1024 && C % 4 == 0 && C >= 4 && C <= 128 && C * r <= 256 && Cout % 16 == 0 && Cout >= 16 && Cout <= 128 &&
            F <= 254 && N <= (1 << 24) && K > 0 && (unsigned long long)N * C * 4ull + 1024ull < (1ull << 32);
 }
 

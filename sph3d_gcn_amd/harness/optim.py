@@ -18,14 +18,19 @@ class FlatAdam:
         self.b1, self.b2, self.eps = float(betas[0]), float(betas[1]), float(eps)
         self.t = 0
         # one group, torch-style, so that `for g in opt.param_groups: g['lr'] = ...` works on both branches
-        self.param_groups = [{"params": [flat_param], "lr": float(lr), "betas": (self.b1, self.b2), "eps": self.eps}]
+        self._groups = [{"params": [flat_param], "lr": float(lr), "betas": (self.b1, self.b2), "eps": self.eps}]
         if flat_param.is_cuda:
             self.m = torch.zeros_like(flat_param.data)
             self.v = torch.zeros_like(flat_param.data)
             self._torch = None
         else:
             self._torch = torch.optim.Adam([flat_param], lr=lr, betas=betas, eps=eps)
-            self.param_groups = self._torch.param_groups
+
+    @property
+    def param_groups(self):
+        # the wrapped optimiser's list is looked up on every access: torch.optim.Optimizer.load_state_dict REPLACES it, an alias
+        # taken at construction would go stale after a resume and a per-step learning-rate decay would be ignored
+        return self._torch.param_groups if self._torch is not None else self._groups
 
     @property
     def lr(self):

@@ -469,10 +469,12 @@ class _MaskedXentFn(torch.autograd.Function):
         inner = inner_label.reshape(B, N).float().contiguous()
         S = _lib.lib().sph3d_masked_softmax_xent_parts(N)
         loss_part = torch.empty((B, S), dtype=torch.float32, device=pred.device)       # a block's loss in S slices of its points
-        dlogits = torch.empty_like(pred)
+        # (evaluation / no_grad: the losses only — no gradient pass, no [B, N, C] store)
+        dlogits = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
         _lib.check(_lib.lib().sph3d_masked_softmax_xent(B, N, C, _lib.ptr(pred), _lib.ptr(label), _lib.ptr(inner),
                                                         _lib.ptr(loss_part), _lib.ptr(dlogits), _lib.stream_ptr()))
-        ctx.save_for_backward(dlogits)
+        if dlogits is not None:
+            ctx.save_for_backward(dlogits)
         return loss_part
 
     @staticmethod

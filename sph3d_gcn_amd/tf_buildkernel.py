@@ -2,17 +2,22 @@
 
 PyTorch custom op ``sph3d::spherical_kernel`` (no gradient, :34).
 
-``set_atan2("ocml")`` switches the angle function from the shared correctly-rounded atan2f (default: the same bits on
-the GPU and in the CPU oracle) to ROCm's device-library atan2f — the function the reference's own kernel calls when it
-is built for this GPU.  In that mode the bins equal the reference build's bit for bit (tests/test_gpu_parity.py); in
-the default mode they differ from it only for neighbours within an ulp of an angular bin boundary (the exact list on
-the golden clouds is pinned in tests/golden/ref_gfx950.json).
+The angle function of the binning has two modes (``set_atan2``):
+
+* ``"ocml"`` — THE DEFAULT: ROCm's device-library atan2f, the function the reference's own kernel calls when it is built
+  for this GPU.  The bins equal the reference build's bit for bit (tests/test_gpu_parity.py, tests/test_gpu_round3.py: all
+  8.4 M level-0 slots of the bench batch); a CPU cannot reproduce them.
+* ``"shared"`` — the correctly rounded atan2f of include/sph3d_atan2f.h, the same bits on the GPU and in the CPU oracle.
+  It differs from the reference build only for neighbours within an ulp of an angular bin boundary (about 0.07 % of the
+  level-0 slots; the exact list on the golden clouds is pinned in tests/golden/ref_gfx950.json).  The oracle-comparison
+  tests select it explicitly (tests/conftest.py).
 """
 import torch
 
-from . import _lib, _plan
+from . import _lib
 
-_atan2 = "shared"
+DEFAULT_ATAN2 = "ocml"
+_atan2 = DEFAULT_ATAN2
 
 
 def set_atan2(which):
@@ -44,10 +49,6 @@ def _spherical_kernel_impl(database: torch.Tensor, query: torch.Tensor, nn_index
     _lib.check(fn(
         B, N, M, K, n_azim, p_elev, q_radi, radius, _lib.ptr(database), _lib.ptr(query),
         _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(nn_dist), _lib.ptr(filt_index), _lib.stream_ptr()))
-    # the convolutions that will use these bins can tile their work spatially: remember which coordinates they came from
-    # (only when the LDS mode is on: the registry pins the tensors)
-    if _plan.get_mode() != "gather":
-        _plan.register_geometry(filt_index, database, query)
     return filt_index
 
 

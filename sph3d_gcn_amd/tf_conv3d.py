@@ -9,7 +9,7 @@ from typing import Tuple
 import torch
 import torch.nn.functional as Fn
 
-from . import _lib, _plan, _tgraph
+from . import _lib, _tgraph
 
 
 def _channel_pad(C, r):
@@ -48,13 +48,6 @@ def _depthwise_conv3d_impl(input: torch.Tensor, filter: torch.Tensor, nn_index: 
         out = _depthwise_conv3d_impl(Fn.pad(input, (0, pad)), Fn.pad(filter, (0, 0, 0, pad)), nn_index, nn_count, bin_index)
         return out[:, :, :C * r].contiguous()
     output = torch.empty((B, M, C * r), dtype=torch.float32, device=input.device)
-    if _plan.applies(N, M, K, F, C, r):
-        # neighbour rows gathered from LDS tiles (csrc/convlds.hip): same arithmetic and summation order, same bits
-        hdr, rec, meta, rows = _plan.conv_plan(nn_index, nn_count, bin_index, F, N)
-        _lib.check(_lib.lib().sph3d_depthwise_conv3d_lds(
-            B, N, M, F, C, r, _lib.ptr(hdr), _lib.ptr(rec), _lib.ptr(meta), _lib.ptr(rows),
-            _lib.ptr(input), _lib.ptr(filter), _lib.ptr(output), _lib.stream_ptr()))
-        return output
     _lib.check(_lib.lib().sph3d_depthwise_conv3d(
         B, N, M, F, C, r, K, _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(bin_index),
         _lib.ptr(input), _lib.ptr(filter), _lib.ptr(output), _lib.stream_ptr()))
@@ -228,12 +221,6 @@ def _depthwise_conv3d_cat_impl(input_a, input_b, filter, nn_index, nn_count, bin
         raise ValueError("Input Channel Size error!")
     M, K = nn_index.shape[1], nn_index.shape[2]
     output = torch.empty((B, M, (Ca + Cb) * r), dtype=torch.float32, device=input_a.device)
-    if Ca % 64 == 0 and _plan.applies(N, M, K, F, Ca + Cb, r):
-        hdr, rec, meta, rows = _plan.conv_plan(nn_index, nn_count, bin_index, F, N)
-        _lib.check(_lib.lib().sph3d_depthwise_conv3d_lds_cat(
-            B, N, M, F, Ca, Cb, r, _lib.ptr(hdr), _lib.ptr(rec), _lib.ptr(meta), _lib.ptr(rows),
-            _lib.ptr(input_a), _lib.ptr(input_b), _lib.ptr(filter), _lib.ptr(output), _lib.stream_ptr()))
-        return output
     _lib.check(_lib.lib().sph3d_depthwise_conv3d_cat(B, N, M, F, Ca, Cb, r, K, _lib.ptr(nn_index), _lib.ptr(nn_count),
                                                      _lib.ptr(bin_index), _lib.ptr(input_a), _lib.ptr(input_b), _lib.ptr(filter),
                                                      _lib.ptr(output), _lib.stream_ptr()))

@@ -42,11 +42,22 @@ def _build_sphere_neighbor_impl(database: torch.Tensor, query: torch.Tensor, rad
     nn_count = torch.empty((B, M), dtype=torch.int32, device=database.device)
     nn_dist = torch.empty((B, M, nn_sample), dtype=torch.float32, device=database.device)
     l = _lib.lib()
-    fn = l.sph3d_build_sphere_neighbor_fixed if _radius_mode == "fixed" else l.sph3d_build_sphere_neighbor
+    # the `_ws` entry points: the search's cell grid lives in memory of OURS (torch's stream-aware allocator), the library
+    # allocates nothing (include/sph3d.h)
+    sws, swsb = _search_workspace(l, B, N, M, database.device)
+    fn = l.sph3d_build_sphere_neighbor_fixed_ws if _radius_mode == "fixed" else l.sph3d_build_sphere_neighbor_ws
     _lib.check(fn(
         B, N, M, nn_sample, radius, _lib.ptr(database), _lib.ptr(query),
-        _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(nn_dist), _lib.stream_ptr()))
+        _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(nn_dist), _lib.ptr(sws), swsb, _lib.stream_ptr()))
     return nn_index, nn_count, nn_dist
+
+
+def _search_workspace(l, B, N, M, device):
+    """-> (tensor or None, bytes): the neighbour search's cell-grid memory for one call (0 bytes: the shape never uses a grid)"""
+    nbytes = l.sph3d_build_sphere_neighbor_workspace(B, N, M)
+    if not nbytes:
+        return None, 0
+    return torch.empty((nbytes,), dtype=torch.uint8, device=device), nbytes
 
 
 _build_sphere_neighbor = torch.library.custom_op("sph3d::build_sphere_neighbor", mutates_args=())(_build_sphere_neighbor_impl)
@@ -127,7 +138,7 @@ def build_sphere_graph(xyz, radius, nnsample, kernel, with_transpose=True):
     kernel)`` — and, with_transpose, the counting pass of the transposed graph the convolution gradients gather over (it is
     finished and cached here, so the backward pass finds it ready).
     -> nn_index, nn_count, nn_dist, filt_index"""
-    from . import _plan, _tgraph
+    from . import _tgraph
     xyz = _lib.f32(xyz[:, :, 0:3])
     _lib.require_device(xyz)
     if _radius_mode == "fixed":
@@ -147,14 +158,12 @@ def build_sphere_graph(xyz, radius, nnsample, kernel, with_transpose=True):
         wsb = l.sph3d_graph_transpose_workspace(B, N, N, K, F)
         ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
     from . import tf_buildkernel
-    # tf_buildkernel.set_atan2("ocml") reaches the fused kernel too: the bins of the reference's own build, bit for bit
-    fn = l.sph3d_build_sphere_graph_ocml if tf_buildkernel._atan2 == "ocml" else l.sph3d_build_sphere_graph
-    _lib.check(fn(B, N, N, K, float(radius), n, p, q, _lib.ptr(xyz), _lib.ptr(xyz), _lib.ptr(nn_index),
-                  _lib.ptr(nn_count), _lib.ptr(nn_dist), _lib.ptr(filt), _lib.ptr(ws), wsb, _lib.stream_ptr()))
-    if _plan.get_mode() != "gather":
-        # the convolutions on this graph gather from LDS tiles: their plan is built here, on the graph stream
-        _plan.register_geometry(filt, xyz, xyz)
-        _plan.prebuild(nn_index, nn_count, filt, F, N)
+    # the atan2 mode of tf_buildkernel reaches the fused kernel too ("ocml", the default: the bins of the reference's own build)
+    sws, swsb = _search_workspace(l, B, N, N, dev)
+    _lib.check(l.sph3d_build_sphere_graph_ws(
+        B, N, N, K, float(radius), n, p, q, 1 if tf_buildkernel._atan2 == "ocml" else 0, _lib.ptr(xyz), _lib.ptr(xyz),
+        _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(nn_dist), _lib.ptr(filt), _lib.ptr(ws), wsb, _lib.ptr(sws), swsb,
+        _lib.stream_ptr()))
     if with_transpose:
         _tgraph.transpose(nn_index, nn_count, N, bin_index=filt, num_bins=F, counted_workspace=ws)
     return nn_index, nn_count, nn_dist, filt
@@ -181,8 +190,9 @@ def build_sphere_neighbor_counted(database, query, radius, nnsample):
     l = _lib.lib()
     wsb = l.sph3d_graph_transpose_workspace(B, N, M, K, 1)
     ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
-    _lib.check(l.sph3d_build_sphere_graph(B, N, M, K, float(radius), 0, 0, 0, _lib.ptr(database), _lib.ptr(query),
-                                          _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(nn_dist), _lib.ptr(None), _lib.ptr(ws), wsb,
-                                          _lib.stream_ptr()))
+    sws, swsb = _search_workspace(l, B, N, M, dev)
+    _lib.check(l.sph3d_build_sphere_graph_ws(B, N, M, K, float(radius), 0, 0, 0, 0, _lib.ptr(database), _lib.ptr(query),
+                                             _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(nn_dist), _lib.ptr(None), _lib.ptr(ws),
+                                             wsb, _lib.ptr(sws), swsb, _lib.stream_ptr()))
     _tgraph.transpose(nn_index, nn_count, N, counted_workspace=ws)
     return nn_index, nn_count, nn_dist

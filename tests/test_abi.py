@@ -52,6 +52,37 @@ def test_host_side_validation_without_gpu():
         _lib.check(rc)
 
 
+def test_search_entry_points_with_caller_workspace():
+    """the `_ws` twins of the neighbour-search entry points (no library allocation: SURVEY 8b) validate like the convenience
+    ones, size their workspace on the host, and the scratch-release hooks answer without a device buffer to free"""
+    from sph3d_gcn_amd import _lib
+    l = _lib.lib()
+    for name in ("sph3d_build_sphere_neighbor_workspace", "sph3d_build_sphere_neighbor_ws", "sph3d_build_sphere_neighbor_fixed_ws",
+                 "sph3d_build_sphere_graph_ws", "sph3d_release_stream_scratch", "sph3d_release_all_scratch"):
+        assert name in _declared()
+    rc = l.sph3d_build_sphere_neighbor_ws(1, 4, 4, 4, -0.5, None, None, None, None, None, None, 0, None)
+    assert rc == -1 and b"radius>0" in l.sph3d_last_error()
+    rc = l.sph3d_build_sphere_graph_ws(1, 4, 4, 4, 0.1, 3, 2, 2, 1, None, None, None, None, None, 1, None, 0, None, 0, None)
+    assert rc == -1 and b"n_" in l.sph3d_last_error()
+    # shapes the cell grid never takes need no workspace; the bench's level 0 does: 16 B per point + 4 B per query + cell starts
+    assert l.sph3d_build_sphere_neighbor_workspace(2, 512, 512) == 0
+    need = l.sph3d_build_sphere_neighbor_workspace(16, 8192, 8192)
+    assert need >= 16 * 8192 * (16 + 4) and need % 4 == 0
+    assert l.sph3d_build_sphere_neighbor_workspace(16, 8192, 2048) < need
+
+
+def test_library_default_bins_are_the_reference_builds():
+    """tf_buildkernel's library-wide default is the device-library atan2f (= the reference build, bit for bit); the tests run in
+    "shared" mode through conftest's fixture"""
+    from sph3d_gcn_amd import tf_buildkernel
+    assert tf_buildkernel.DEFAULT_ATAN2 == "ocml"
+    assert tf_buildkernel._atan2 == "shared"          # this test runs under the fixture
+    import subprocess, sys
+    out = subprocess.run([sys.executable, "-c", "from sph3d_gcn_amd import tf_buildkernel as t; print(t._atan2)"], cwd=ROOT,
+                         capture_output=True, text=True)
+    assert out.stdout.strip() == "ocml", out.stderr[-400:]
+
+
 def test_ops_refuse_cpu_tensors():
     import torch
     from sph3d_gcn_amd import tf_sample, tf_nnquery, _lib

@@ -281,3 +281,36 @@ def test_bench_algorithmic_bytes_follow_the_survey_formulas():
     # both gradients in one call: read input, graph, counts, filter, grad_out; write grad_input and grad_filter
     bwd = bench.algorithmic_bytes("sph3d_depthwise_conv3d_grad_t", (B, N, M, F, C, r))
     assert bwd == 336136192
+
+
+def test_flat_adam_learning_rate_survives_a_resume_on_the_cpu_branch():
+    """torch.optim.Optimizer.load_state_dict replaces param_groups; FlatAdam.lr / param_groups must keep writing
+    to the list the wrapped optimiser actually reads"""
+    from sph3d_gcn_amd.harness import optim
+    p = torch.nn.Parameter(torch.ones(8))
+    opt = optim.FlatAdam(p, lr=1e-2)
+    p.grad = torch.ones(8)
+    opt.step()
+    state = opt.state_dict()
+    opt.load_state_dict(state)
+    opt.lr = 0.0                                   # a decayed rate after the resume ...
+    assert opt._torch.param_groups[0]["lr"] == 0.0 and opt.param_groups is opt._torch.param_groups
+    before = p.detach().clone()
+    opt.step()                                     # ... must be the one the step uses
+    assert torch.equal(p.detach(), before)
+    for g in opt.param_groups:
+        g["lr"] = 1e-2
+    opt.step()
+    assert not torch.equal(p.detach(), before)
+
+
+def test_fused_separable_layer_support_is_what_the_launcher_can_run():
+    """sph3d_separable_conv3d_fused_supported folds the LDS fit in: a kernel with more bins than fit beside the
+    smallest tile is reported unsupported (the layer then runs layer by layer) instead of failing at launch"""
+    from sph3d_gcn_amd import _lib
+    l = _lib.lib()
+    assert l.sph3d_separable_conv3d_fused_supported(8192, 33, 128, 2, 64, 128) == 1       # the S3DIS plan's [8,2,2] kernel
+    assert l.sph3d_separable_conv3d_fused_supported(8192, 49, 256, 2, 64, 256) == 1       # [8,2,3]
+    assert l.sph3d_separable_conv3d_fused_supported(8192, 97, 256, 2, 64, 256) == 1       # [8,4,3]: fits with a lower tile
+    assert l.sph3d_separable_conv3d_fused_supported(8192, 161, 256, 2, 64, 256) == 0      # 162 KB of filter slice alone
+    assert l.sph3d_separable_conv3d_fused_supported(8192, 254, 128, 2, 64, 128) == 0

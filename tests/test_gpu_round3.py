@@ -862,6 +862,38 @@ def test_masked_softmax_cross_entropy_kernel_equals_the_framework_formula(dev):
         assert float(grad[0].abs().max()) == 0.0
 
 
+def test_loss_kernel_flags_labels_out_of_range_and_skips_the_gradient_without_grad(dev):
+    """an inner point with a label outside [0, C) makes its block's loss and its gradient row NaN (never a silently
+    clamped class: the CPU path raises, the reference's GPU op yields NaN); other blocks are untouched.  Under no_grad the
+    kernel computes the losses only (dlogits == NULL)."""
+    import torch
+    from sph3d_gcn_amd.harness import s3dis_net
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B, N, C = 3, 2000, 13
+    logits = torch.randn((B, N, C), generator=g).to(dev)
+    label = torch.randint(0, C, (B, N), generator=g).to(dev)
+    inner = torch.ones((B, N)).to(dev)
+    with torch.no_grad():
+        clean = s3dis_net._MaskedXentFn.apply(logits, label, inner).sum(dim=1)
+    lg = logits.clone().requires_grad_(True)
+    with_grad = s3dis_net._MaskedXentFn.apply(lg, label, inner).sum(dim=1)
+    assert torch.equal(clean, with_grad.detach())                       # same losses with and without the gradient pass
+    bad = label.clone()
+    bad[1, 77] = C                                                      # one bad label in block 1
+    bad[1, 1500] = -3
+    inner2 = inner.clone()
+    bad[2, 5] = 99
+    inner2[2, 5] = 0.0                                                  # a bad label on a point that is not inner: ignored
+    out = s3dis_net._MaskedXentFn.apply(lg, bad, inner2)
+    per_block = out.sum(dim=1)
+    (grad,) = torch.autograd.grad(per_block[0] + per_block[2], lg, retain_graph=True)
+    assert torch.isfinite(per_block[0]) and torch.isfinite(per_block[2]) and torch.isnan(per_block[1])
+    assert torch.isfinite(grad).all()
+    (g1,) = torch.autograd.grad(out.sum(), lg)
+    assert torch.isnan(g1[1, 77]).all() and torch.isnan(g1[1, 1500]).all()
+    assert torch.isfinite(g1[1, 78]).all() and torch.isfinite(g1[0]).all() and torch.isfinite(g1[2]).all()
+
+
 def test_plans_on_rotating_sampling_streams_give_the_same_forward(dev):
     """harness: with SAMPLING_STREAMS = 2 and a ready event, the plans of consecutive forwards are built side by side on two
     sampling streams (the forward-only bench line): logits identical to the one-stream order, batch after batch"""

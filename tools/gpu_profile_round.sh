@@ -34,13 +34,13 @@ PY
 if [ -z "$PROFILE_LIGHT" ]; then
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $pass | cut -c1-3)
-  for cfg in "fwd:LDS=" "fwdl:LDS=1" "bwd:LDS="; do
+  for cfg in "fwd:" "bwd:"; do
     name=${cfg%%:*}; env=${cfg#*:}; mode=fwd; [ "$name" = "bwd" ] && mode=bwd
     bash tools/gpu_pmc3.sh ${TAG}_${name}_$n tools/exp_conv_pmc.py "$env MODE=$mode C=128" "$pass" dwconv | tail -2
   done
 done
 # SQ counters: the conv gather / gradient (instruction mix, waits) and the GEMMs (MFMA pipe busy cycles)
-for cfg in "fwd:MODE=fwd" "bwd:MODE=bwd" "fwdl:MODE=fwd LDS=1"; do
+for cfg in "fwd:MODE=fwd" "bwd:MODE=bwd"; do
   name=${cfg%%:*}; env=${cfg#*:}
   bash tools/gpu_pmc3.sh ${TAG}_sq1_$name tools/exp_conv_pmc.py "$env C=128" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" dwconv | tail -2
   bash tools/gpu_pmc3.sh ${TAG}_sq2_$name tools/exp_conv_pmc.py "$env C=128" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" dwconv | tail -2

@@ -31,7 +31,6 @@ def traffic(tag, pat, extra=None):
 for key, tag, pat, extra in (
         ("sph3d_depthwise_conv3d[16, 8192, 8192, 33, 128, 2, 64]", "fwd", "dwconv_fwd_multi", None),
         ("sph3d_depthwise_conv3d_grad_t[16, 8192, 8192, 33, 128, 2]", "bwd", "dwconv_bwd_t_vec<2, 4, 17", None),
-        ("sph3d_depthwise_conv3d_lds[16, 8192, 8192, 33, 128, 2]", "fwdl", "dwconv_fwd_lds", None),
         ("sph3d_pointwise_gemm[131072, 256, 128, 0, 0]", "gemmnn", "gemm_f32_mfma", None),
         ("sph3d_pointwise_gemm_bnstats[131072, 256, 128]", "gemmnn", "gemm_f32_mfma", None),
         ("sph3d_pointwise_gemm_tn[32768, 1024, 128]", "gemmtn", "gemm_f32_mfma", "gemm_reduce_splits"),
