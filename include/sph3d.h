@@ -286,9 +286,12 @@ int sph3d_weighted_interpolate_grad(int B, int N, int M, int C, int K,
  * inp[b,n,3] -> out[b,m] i32; index 0 first, then argmax of the running
  * minimum squared distance; ties: lower (k mod 1024) wins, then lower k
  * (the reference's thread/tree order, :49,:56-66).  Race-free (the reference
- * has a latent race at :68).
+ * has a latent race at :68).  Clouds of 2049 .. 16384 points run a PRUNED form of
+ * the same chain (csrc/sample.hip: fps_prune_kernel): spatially sorted blobs of 64
+ * points whose distance update is skipped when the new sample provably cannot
+ * lower any of their running distances; same samples bit for bit.
  * workspace: sph3d_farthest_point_sample_workspace(b,n,m) bytes (0 when the
- * cloud fits the register-resident kernel, n <= 16384). */
+ * cloud fits the register-resident kernels, n <= 24576). */
 size_t sph3d_farthest_point_sample_workspace(int b, int n, int m);
 int sph3d_farthest_point_sample(int b, int n, int m, const float* inp, int* out,
                                 void* workspace, size_t workspace_bytes,
