@@ -144,6 +144,51 @@ def run_timed(one_step, steps, warmup, world, sync):
     return elapsed, loss
 
 
+def probe_host_issue(model, flat, opt, batch, dev, steps=12):
+    """ms the host needs to issue one training step: the step on ONE block of the batch (wall clock per step with the device
+    nearly idle: it finishes each step long before the host has issued the next)"""
+    pts, label, inner = (t[:1].contiguous() for t in batch)
+    torch.cuda.synchronize()
+    ev = torch.cuda.Event()
+    ev.record()
+    _PTS_READY[pts.data_ptr()] = ev
+
+    def step():
+        return train_step(model, flat, opt, pts, label, inner)      # (N > 1: with its collective — every rank runs the probe)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    _PTS_READY.pop(pts.data_ptr(), None)
+    return (t1 - t0) / steps * 1e3
+
+
+def probe_fps_chain(pts, config, reps=3):
+    """ms of the sampling chain (the plan's farthest-point samplings, level after level) of one batch, alone on the device"""
+    from sph3d_gcn_amd import sph3gcn_util as s3g
+    xyz = pts[:, :, 0:3].contiguous()
+
+    def chain():
+        cur = xyz
+        for m in config.num_sample:
+            if m > 1:
+                idx = s3g.farthest_point_sample(m, cur)
+                cur = torch.gather(cur, 1, idx.long().unsqueeze(2).expand(-1, -1, 3)).contiguous()
+    chain()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        chain()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
 def reduce_max_seconds(elapsed, world, dev):
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -631,6 +676,14 @@ def main():
     flat.time_wait_events = False
     ar_wait_ms = [a.elapsed_time(b) for a, b in flat.wait_events]
 
+    # what this rank's Python needs to ISSUE a step, whatever the device does: the same step on ONE block (the same ~450 launches,
+    # a sixteenth of the device work) and the per-rank time of the sampling chain alone —
+    # a multi-GPU run whose ranks sit well above the 1-GPU ms/step is launch-bound where host_issue approaches that figure, and
+    # device-bound where it does not
+    host_issue_ms, fps_chain_ms = probe_host_issue(model, flat, opt, batches[0], dev), probe_fps_chain(batches[0][0], model.config)
+    per_rank_issue = hdist.gather_floats(host_issue_ms, world, dev)
+    per_rank_fps = hdist.gather_floats(fps_chain_ms, world, dev)
+
     # every rank's own time for the K timed steps (diagnosis of a slow rank), then the contract's MAX over ranks
     per_rank_s = hdist.gather_floats(elapsed, world, dev)
     elapsed = reduce_max_seconds(elapsed, world, dev)
@@ -754,6 +807,9 @@ def main():
             "dist": {"per_rank_ms_per_step": [round(x / args.steps * 1e3, 3) for x in per_rank_s],
                      "rank_ms_per_step_min_max": [round(min(per_rank_s) / args.steps * 1e3, 3),
                                                   round(max(per_rank_s) / args.steps * 1e3, 3)],
+                     "host_issue_ms_per_step_one_block": [round(x, 3) for x in per_rank_issue],
+                     "fps_chain_ms_per_step": [round(x, 3) for x in per_rank_fps],
+                     "cpus_per_rank": pinned_cpus,
                      "bucket_bytes": [4 * (f1 - f0) for (_i0, _i1, f0, f1) in flat.buckets],
                      "buckets_started_in_backward": flat.stats["buckets_started_in_backward"],
                      "buckets_started_after_backward": flat.stats["buckets_started_after_backward"],

@@ -229,3 +229,21 @@ def i32(t):
 def ptr(t):
     """device address for a void* argument (ctypes converts the int; None = NULL)"""
     return t.data_ptr() if t is not None else None
+
+
+# ---- per-stream scratch for workspaces that are dead when the call returns (gradient slabs, split-K slabs, statistics
+# partials): one grow-only buffer per (stream, slot) instead of a torch.empty per call (the step makes ~80 such allocations;
+# work on one stream is ordered, so consecutive calls may share the bytes).  NOT for memory a later call reads.
+_scratch = {}
+
+
+def scratch(nbytes, device, slot=0):
+    """-> a uint8 tensor of at least nbytes on `device` for the current stream, or None for nbytes == 0"""
+    if not nbytes:
+        return None
+    key = (current_raw_stream(), slot)
+    t = _scratch.get(key)
+    if t is None or t.numel() < nbytes or t.device != device:
+        t = torch.empty((nbytes + nbytes // 4,), dtype=torch.uint8, device=device)
+        _scratch[key] = t
+    return t

@@ -64,6 +64,17 @@ def peek(nn_index, nn_count, n_src, need_unique_rows=False):
     return transpose(nn_index, nn_count, n_src)
 
 
+def _attach(nn_index, fkey, hit, nn_count, bin_index, weight):
+    fast = nn_index.__dict__.get("_sph3d_tg")
+    if fast is None:
+        fast = nn_index._sph3d_tg = {}
+    out, _keep, ev, synced = hit
+    # (no reference back to nn_index: a cycle would keep a dropped graph's tensors until the cyclic collector runs)
+    fast[fkey] = ((out, (nn_count, bin_index, weight), ev, synced),
+                  (nn_index._version, nn_count._version, 0 if bin_index is None else bin_index._version,
+                   0 if weight is None else weight._version))
+
+
 def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1, counted_workspace=None, unique_rows=False):
     """-> (offsets[B*(n_src*F+1)] i32, ent_key[B*M*K] i32, ent_scale[B*M*K] f32, active_bins[F+1] i32 | None) on
     nn_index's device; F = num_bins (the filter's bin count when bin_index is given, else 1); active_bins (count, then
@@ -71,10 +82,30 @@ def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1
     phase has already run (tf_nnquery.build_sphere_graph did it inside the neighbour search): only scan + fill remain.
     unique_rows: the caller's promise that no row lists a point twice (rows of the ball query and rows gathered from them)"""
     F = int(num_bins) if bin_index is not None else 1
+    cur_raw = _lib.current_raw_stream()
+    # fast path (the backward pass asks 50 times per step): the entry hangs on the nn_index tensor object itself, keyed by the
+    # identities of the other tensors (which the entry keeps alive, so an id cannot be recycled under it); in-place edits are
+    # caught by the version counters
+    fkey = (id(nn_count), id(bin_index), id(weight), n_src, F)
+    fast = nn_index.__dict__.get("_sph3d_tg")
+    if fast is not None and not unique_rows:
+        fhit = fast.get(fkey)
+        if fhit is not None:
+            hit, vers = fhit
+            if vers == (nn_index._version, nn_count._version, 0 if bin_index is None else bin_index._version,
+                        0 if weight is None else weight._version):
+                out, _keep, ev, synced = hit
+                if cur_raw not in synced:
+                    cur = torch.cuda.current_stream()
+                    cur.wait_event(ev)
+                    for t in out:
+                        if t is not None:
+                            t.record_stream(cur)
+                    synced.add(cur_raw)
+                return out
     key = (_ident(nn_index), _ident(nn_count), _ident(bin_index), _ident(weight), int(n_src), F, tuple(nn_index.shape))
     if unique_rows:
         _unique.add(key)
-    cur_raw = _lib.current_raw_stream()
     hit = _cache.get(key)
     if hit is not None:
         _cache.move_to_end(key)
@@ -86,6 +117,7 @@ def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1
                 if t is not None:
                     t.record_stream(cur)
             synced.add(cur_raw)
+        _attach(nn_index, fkey, hit, nn_count, bin_index, weight)
         return out
     cur = torch.cuda.current_stream()
     B, M, K = nn_index.shape
@@ -116,6 +148,7 @@ def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1
     ev = torch.cuda.Event()
     ev.record(cur)
     _cache[key] = (out, (nn_index, nn_count, bin_index, weight), ev, {cur_raw})
+    _attach(nn_index, fkey, _cache[key], nn_count, bin_index, weight)
     while len(_cache) > _MAX_ENTRIES:
         _unique.discard(_cache.popitem(last=False)[0])
     return out

@@ -83,7 +83,7 @@ def _depthwise_conv3d_grad_impl(input: torch.Tensor, filter: torch.Tensor, grad_
     offsets, ent_key, ent_scale, active = _tgraph.transpose(nn_index, nn_count, N, bin_index=bin_index, num_bins=F)
     l = _lib.lib()
     wsb = l.sph3d_depthwise_conv3d_grad_t_workspace(B, N, F, C, r)
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=input.device) if wsb else None
+    ws = _lib.scratch(wsb, input.device)
     _lib.check(l.sph3d_depthwise_conv3d_grad_t(
         B, N, M, F, C, r, _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale),
         _lib.ptr(_tgraph.source_order(nn_index)), _lib.ptr(active),
@@ -238,7 +238,7 @@ def _depthwise_conv3d_cat_grad_impl(input_a, input_b, filter, grad_output, nn_in
     offsets, ent_key, ent_scale, active = _tgraph.transpose(nn_index, nn_count, N, bin_index=bin_index, num_bins=F)
     l = _lib.lib()
     wsb = l.sph3d_depthwise_conv3d_grad_t_workspace(B, N, F, Ca + Cb, r)
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=input_a.device) if wsb else None
+    ws = _lib.scratch(wsb, input_a.device)
     _lib.check(l.sph3d_depthwise_conv3d_grad_t_cat(
         B, N, M, F, Ca, Cb, r, _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale), _lib.ptr(_tgraph.source_order(nn_index)),
         _lib.ptr(active), _lib.ptr(input_a), _lib.ptr(input_b), _lib.ptr(filter), _lib.ptr(grad_output), _lib.ptr(grad_a),

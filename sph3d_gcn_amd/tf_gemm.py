@@ -39,7 +39,7 @@ def _pointwise_gemm_tn_impl(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     dw = torch.empty((Cin, Cout), dtype=torch.float32, device=x.device)
     l = _lib.lib()
     wsb = l.sph3d_pointwise_gemm_tn_workspace(R, Cin, Cout)
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device) if wsb else None
+    ws = _lib.scratch(wsb, x.device)
     _lib.check(l.sph3d_pointwise_gemm_tn(R, Cin, Cout, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(ws), wsb,
                                          _lib.stream_ptr()))
     return dw
@@ -167,7 +167,7 @@ def _skinny_tn_impl(a1: torch.Tensor, a2: torch.Tensor, dy: torch.Tensor) -> tor
     N = dy.shape[1]
     l = _lib.lib()
     wsb = l.sph3d_pointwise_gemm_skinny_tn_workspace(R, K1, K2, N)
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=a1.device)
+    ws = _lib.scratch(wsb, a1.device)
     dw = torch.empty((K1 + K2, N), dtype=torch.float32, device=a1.device)
     _lib.check(l.sph3d_pointwise_gemm_skinny_tn(R, K1, K2, N, _lib.ptr(a1), _lib.ptr(a2), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(ws), wsb,
                                                 _lib.stream_ptr()))

@@ -57,7 +57,7 @@ def _search_workspace(l, B, N, M, device):
     nbytes = l.sph3d_build_sphere_neighbor_workspace(B, N, M)
     if not nbytes:
         return None, 0
-    return torch.empty((nbytes,), dtype=torch.uint8, device=device), nbytes
+    return _lib.scratch(nbytes, device, slot=1), nbytes          # (slot 1: the call also holds a transpose workspace)
 
 
 _build_sphere_neighbor = torch.library.custom_op("sph3d::build_sphere_neighbor", mutates_args=())(_build_sphere_neighbor_impl)

@@ -30,7 +30,7 @@ def _fwd_impl(y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, moving_m
     save_rstd = torch.empty((C,), dtype=torch.float32, device=y.device)
     l = _lib.lib()
     wsb = l.sph3d_elu_bn_workspace(R, C)
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=y.device)
+    ws = _lib.scratch(wsb, y.device)
     _lib.check(l.sph3d_elu_bn_forward(R, C, _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(moving_mean),
                                       _lib.ptr(moving_var), 1.0 - MOMENTUM, EPSILON, 1 if training else 0, _lib.ptr(out),
                                       _lib.ptr(save_mean), _lib.ptr(save_rstd), _lib.ptr(ws), wsb, _lib.stream_ptr()))
@@ -48,7 +48,7 @@ def _bwd_impl(y: torch.Tensor, dout: torch.Tensor, gamma: torch.Tensor, save_mea
     dbeta = torch.empty((C,), dtype=torch.float32, device=y.device)
     l = _lib.lib()
     wsb = l.sph3d_elu_bn_workspace(R, C)
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=y.device)
+    ws = _lib.scratch(wsb, y.device)
     _lib.check(l.sph3d_elu_bn_backward(R, C, _lib.ptr(y), _lib.ptr(dout), _lib.ptr(gamma), _lib.ptr(save_mean),
                                        _lib.ptr(save_rstd), 1 if training else 0, _lib.ptr(dy), _lib.ptr(dgamma),
                                        _lib.ptr(dbeta), _lib.ptr(ws), wsb, _lib.stream_ptr()))

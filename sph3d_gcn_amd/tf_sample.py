@@ -20,7 +20,7 @@ def _farthest_point_sample_impl(database: torch.Tensor, npoint: int) -> torch.Te
     out = torch.empty((b, npoint), dtype=torch.int32, device=database.device)
     l = _lib.lib()
     wsb = l.sph3d_farthest_point_sample_workspace(b, n, npoint)
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=database.device) if wsb else None
+    ws = _lib.scratch(wsb, database.device)
     _lib.check(l.sph3d_farthest_point_sample(b, n, npoint, _lib.ptr(database), _lib.ptr(out), _lib.ptr(ws), wsb,
                                              _lib.stream_ptr()))
     return out
