@@ -141,6 +141,7 @@ def timing_stop():
     return out
 
 
+_PURE = ("_workspace", "_blocks", "_supported", "_parts")
 _NO_TIME = ("sph3d_abi_version", "sph3d_last_error", "sph3d_build_info", "workspace", "_release_", "_blocks", "_supported", "_launches", "_parts")
 
 
@@ -155,6 +156,18 @@ class _Proxy:
         # (reached once per symbol: the result is stored on the instance, so later look-ups never come here — 180 look-ups per
         # step at 2 us each otherwise)
         fn = getattr(self._cdll, name)     # AttributeError if not exported
+        if any(k in name for k in _PURE):
+            # pure functions of their integer arguments (workspace sizes, shape predicates): a step asks ~75 of them, always
+            # for the same shapes — answered from a dict instead of a foreign call each time
+            memo = {}
+
+            def cached(*args, _fn=fn, _memo=memo):
+                r = _memo.get(args)
+                if r is None:
+                    r = _memo[args] = _fn(*args)
+                return r
+            self.__dict__[name] = cached
+            return cached
         if any(k in name for k in _NO_TIME):
             self.__dict__[name] = fn
             return fn

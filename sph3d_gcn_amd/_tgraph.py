@@ -21,10 +21,14 @@ def _ident(t):
     return (0, 0) if t is None else (t.data_ptr(), t._version)
 
 
+_generation = [0]      # bumped by clear(): entries attached to graph tensors (transpose's fast path) from before are ignored
+
+
 def clear():
     _cache.clear()
     _orders.clear()
     _unique.clear()
+    _generation[0] += 1
 
 
 # processing order of the source points of a graph (a permutation per cloud, spatially sorted): optional hint for
@@ -71,7 +75,7 @@ def _attach(nn_index, fkey, hit, nn_count, bin_index, weight):
     out, _keep, ev, synced = hit
     # (no reference back to nn_index: a cycle would keep a dropped graph's tensors until the cyclic collector runs)
     fast[fkey] = ((out, (nn_count, bin_index, weight), ev, synced),
-                  (nn_index._version, nn_count._version, 0 if bin_index is None else bin_index._version,
+                  (_generation[0], nn_index._version, nn_count._version, 0 if bin_index is None else bin_index._version,
                    0 if weight is None else weight._version))
 
 
@@ -92,7 +96,7 @@ def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1
         fhit = fast.get(fkey)
         if fhit is not None:
             hit, vers = fhit
-            if vers == (nn_index._version, nn_count._version, 0 if bin_index is None else bin_index._version,
+            if vers == (_generation[0], nn_index._version, nn_count._version, 0 if bin_index is None else bin_index._version,
                         0 if weight is None else weight._version):
                 out, _keep, ev, synced = hit
                 if cur_raw not in synced:
