@@ -66,8 +66,8 @@ def tr(pat, col="mean_us", grid=None):
 tu = t.setdefault("trace_us", {})
 tu["sph3d_depthwise_conv3d[16, 8192, 8192, 33, 128, 2, 64]"] = tr("dwconv_fwd_multi<2, 32, 4>")
 tu["sph3d_depthwise_conv3d[16, 8192, 8192, 33, 64, 2, 64]"] = tr("dwconv_fwd_multi<2, 16, 4>")
-tu["sph3d_depthwise_conv3d_grad_t[16, 8192, 8192, 33, 64, 2]"] = tr("dwconv_bwd_t_vec<2, 4, 17, true, true>")
-tu["sph3d_depthwise_conv3d_grad_t[16, 8192, 8192, 33, 128, 2]"] = tr("dwconv_bwd_t_vec<2, 4, 17, false, true>", "max_us", 262144)
+tu["sph3d_depthwise_conv3d_grad_t[16, 8192, 8192, 33, 64, 2]"] = tr("dwconv_bwd_t_vec<2, 4, 17, 2, true>")
+tu["sph3d_depthwise_conv3d_grad_t[16, 8192, 8192, 33, 128, 2]"] = tr("dwconv_bwd_t_vec<2, 4, 17, 1, true>", "max_us", 262144)
 
 
 def dur_us(path, pat):
