@@ -589,6 +589,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probes", action="store_true", help="skip the one-block host-issue and sampling-chain probes of `dist`")
     ap.add_argument("--atan2", choices=("ocml", "shared"), default="ocml",
                     help="angle function of the spherical-kernel binning: 'ocml' = ROCm's device-library atan2f, the function the "
                          "reference's own kernel calls when built for this GPU (bins bit-identical to the reference build); "
@@ -680,7 +681,10 @@ def main():
     # a sixteenth of the device work) and the per-rank time of the sampling chain alone —
     # a multi-GPU run whose ranks sit well above the 1-GPU ms/step is launch-bound where host_issue approaches that figure, and
     # device-bound where it does not
-    host_issue_ms, fps_chain_ms = probe_host_issue(model, flat, opt, batches[0], dev), probe_fps_chain(batches[0][0], model.config)
+    if args.no_probes:            # (the rocprofv3 run of tools/gpu_profile_round.sh: its kernel statistics must hold whole 16-block steps only)
+        host_issue_ms, fps_chain_ms = 0.0, 0.0
+    else:
+        host_issue_ms, fps_chain_ms = probe_host_issue(model, flat, opt, batches[0], dev), probe_fps_chain(batches[0][0], model.config)
     per_rank_issue = hdist.gather_floats(host_issue_ms, world, dev)
     per_rank_fps = hdist.gather_floats(fps_chain_ms, world, dev)
 

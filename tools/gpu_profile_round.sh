@@ -11,7 +11,7 @@ timeout 900 python bench.py > $OUT/${TAG}_bench_default.log 2> $OUT/${TAG}_bench
 # secondary lines (BASELINE configs 2, 3, 5 and the inference forward): same contract, not the headline
 for c in modelnet shapenet scannet; do timeout 400 python bench.py --config $c --steps 20 --warmup 3 > $OUT/${TAG}_bench_$c.log 2> $OUT/${TAG}_bench_$c.err; done
 timeout 400 python bench.py --eval --steps 20 --warmup 3 > $OUT/${TAG}_bench_eval.log 2> $OUT/${TAG}_bench_eval.err
-cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_prof.log 2>&1; echo "prof rc=$?"
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-probes > $OUT/${TAG}_prof.log 2>&1; echo "prof rc=$?"
 cd $GRAFT_REPO_ROOT
 python - <<PY
 import csv, glob, collections, shutil
