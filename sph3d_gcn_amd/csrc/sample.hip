@@ -161,7 +161,8 @@ __global__ __launch_bounds__(1024) void fps_reg_kernel(int b, int n, int m,
 //     active wave (1.06 us per round at 8192 points against 1.09 for the plain kernel); 4 or 8 waves with 32 / 16 points per
 //     lane (1.53 / 1.15: fewer waves hide less of each other's latency); updating ALL slots of an active wave in straight-line
 //     code instead of branching per slot (0.95, 1.10 with the blobs dealt in turn); a wave owning P CONSECUTIVE blobs (0.97).
-//     This form: 0.89 us per round at 8192 points (plain 1.10), 1.01 at 10 000 (1.39), 0.74 at 4096 (0.77), a tie at 2048;
+//     This form (with the atomic-max exchange below): 0.83 us per round at 8192 points (plain 1.10), 1.03 at 10 000 (1.39),
+//     0.71 at 4096 (0.77), 0.70 at 2500 (0.78); at 2048 the plain kernel stays ahead (0.62 against 0.70);
 //   * the reference's tie-break (tf_sample_gpu.cu:49,56-66: larger distance, then lower thread id k mod 1024, then lower k)
 //     no longer follows from the thread mapping — the points are permuted — so it is carried explicitly: a point's key is
 //     (bits of td) << 32 | sec(k), sec(k) = (1023 - k mod 1024) << 8 | (255 - k div 1024); the largest key wins and the
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(64 * NW) void fps_prune_kernel(int b, int n, int m,
     __shared__ float red[6][NW];
     __shared__ int wsum[NW];
     __shared__ FpsSlotP slots[2][NW];
-    __shared__ unsigned slot_sec[2][NW];
+    __shared__ u64 cell[3];
     const int t = (int)threadIdx.x;
     const int lane = t & 63;
     const int wave = uniform(t >> 6);
@@ -368,6 +369,9 @@ __global__ __launch_bounds__(64 * NW) void fps_prune_kernel(int b, int n, int m,
         float c_x = 0.f, c_y = 0.f, c_z = 0.f;
         u64 kb = 0ull;
         int bp = 0;
+        int c3 = 1;                                            // j mod 3
+        if (t < 3) cell[t] = 0ull;
+        __syncthreads();
 
 #ifdef SPH3D_FPS_PROF
         unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // own work (active / idle rounds), their counts, publish + barrier, post, rescans, slots updated
@@ -430,31 +434,37 @@ __global__ __launch_bounds__(64 * NW) void fps_prune_kernel(int b, int n, int m,
                 c_vb = wmb;
             }
             const unsigned long long tk1 = FPS_CLK(); (void)tk1;
+            // ---- exchange: every wave publishes its candidate's coordinates and raises the round's cell to its key with ONE LDS
+            // atomic max: (distance bits) << 32 | sec << 4 | wave — the largest key is the reference's winner (sec is unique per
+            // point, so the wave bits never decide) and names the slot that holds its coordinates.  After the barrier a wave reads
+            // the cell and that slot: ~10 instructions, where reducing the 16 candidates inside every wave (LDS read, six DPP steps,
+            // ballots, read-lanes) took 35 — and the SIMD issues the post-barrier code of its four waves one after the other
+            // (cycle counters: 450 cycles for the oldest wave of a SIMD, 790 for the youngest; 320-430 with the cell).  The plain
+            // kernel above keeps its reduction: there all 16 waves reach the exchange together and their atomics on one address
+            // queue up on the round's critical path (0.70 instead of 0.62 us per round at 2048 points); here the idle waves'
+            // atomics are long done when the waves with work arrive.  Cells rotate over three rounds:
+            // the one of round j + 2 is cleared after barrier j, when round j - 1's readers are done and before barrier j + 1 lets
+            // round j + 2's writers through.
             const int buf = j & 1;
             if (lane == 0) {
                 FpsSlotP sl;
                 sl.vbits = c_vb; sl.x = c_x; sl.y = c_y; sl.z = c_z;
                 slots[buf][wave] = sl;
-                slot_sec[buf][wave] = c_sec;
+                __hip_atomic_fetch_max(&cell[c3], ((u64)c_vb << 32) | ((u64)c_sec << 4) | (u64)wave, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             __syncthreads();
             const unsigned long long tk2 = FPS_CLK(); (void)tk2;
-            // ---- every wave: the NW candidates -> the round's winner ----
-            const FpsSlotP s = slots[buf][lane & (NW - 1)];
-            const unsigned ssec = slot_sec[buf][lane & (NW - 1)];
-            const unsigned gmax = wave_max_u32(s.vbits);
-            const u64 gt = __ballot(s.vbits == gmax) & ((1ull << NW) - 1ull);
-            int gw = (int)__builtin_ctzll(gt);
-            if (gt & (gt - 1ull)) {                            // several waves hold the same distance: sec decides (rare)
-                const unsigned ss = (s.vbits == gmax) ? ssec : 0u;
-                const unsigned gs = wave_max_u32(ss);
-                gw = (int)__builtin_ctzll(__ballot(s.vbits == gmax && ss == gs) & ((1ull << NW) - 1ull));
-            }
-            const unsigned gsec = (unsigned)__builtin_amdgcn_readlane((int)ssec, gw);
-            x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.x), gw));
-            y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.y), gw));
-            z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.z), gw));
-            g = __uint_as_float(gmax);
+            const u64 win = cell[c3];                              // the same address in every lane: a broadcast read
+            const int c3n = c3 == 2 ? 0 : c3 + 1;
+            if (t == 0) cell[c3n == 2 ? 0 : c3n + 1] = 0ull;       // = (c3 + 2) % 3
+            c3 = c3n;
+            const FpsSlotP s = slots[buf][(int)(win & 15ull)];
+            const unsigned gsec = (unsigned)(win >> 4) & 0x3ffffu;
+            x1 = uniformf(s.x);
+            y1 = uniformf(s.y);
+            z1 = uniformf(s.z);
+            g = uniformf(__uint_as_float((unsigned)(win >> 32)));
             if (t == 0) {
                 // sec -> k; sec == 0: no point at all (cannot happen for n >= 1) -> the reference's idle-thread index 0
                 const int k = gsec != 0u ? (((255 - (int)(gsec & 255u)) << 10) | (1023 - (int)(gsec >> 8))) : 0;
