@@ -63,3 +63,15 @@ def test_pruned_fps_ties_duplicates_and_clusters(dev):
     np.testing.assert_array_equal(_fps(dev, line, 500), oracle.farthest_point_sample(500, line))
     same = np.full((1, 1500, 3), 0.25, np.float32)
     np.testing.assert_array_equal(_fps(dev, same, 20), oracle.farthest_point_sample(20, same))
+
+
+def test_pruned_fps_with_non_finite_coordinates(dev):
+    """NaN / Inf coordinates: the box tests turn conservative (a NaN never lets a slot be skipped), the samples stay the oracle's"""
+    rng = np.random.RandomState(9)
+    pts = rng.rand(2, 4096, 3).astype(np.float32)
+    pts[0, 100] = (np.nan, 0.5, 0.5)
+    pts[0, 2000, 2] = np.inf
+    pts[1, 7, 0] = -np.inf
+    with np.errstate(invalid="ignore", over="ignore"):
+        want = oracle.farthest_point_sample(300, pts)
+    np.testing.assert_array_equal(_fps(dev, pts, 300), want)
