@@ -22,6 +22,33 @@
 
 namespace sph3d {
 
+__global__ __launch_bounds__(256) void zero_fill_kernel(unsigned* __restrict__ p, size_t words)
+{
+    // the 16-byte aligned body as uint4 stores, the (at most 3 + 3) words around it one by one
+    const size_t head = ((16 - (reinterpret_cast<size_t>(p) & 15)) & 15) >> 2;
+    const size_t h = head < words ? head : words;
+    uint4* q = reinterpret_cast<uint4*>(p + h);
+    const size_t quads = (words - h) >> 2;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t i = t; i < quads; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (t < h) p[t] = 0u;
+    const size_t tail0 = h + (quads << 2);
+    if (t < words - tail0) p[tail0 + t] = 0u;
+}
+
+int zero_async(void* p, size_t bytes, hipStream_t stream, const char* what)
+{
+    if (bytes == 0) return SPH3D_OK;
+    if (bytes < (256u << 10) || (bytes & 3) != 0 || (reinterpret_cast<size_t>(p) & 3) != 0)
+        return check_hip(hipMemsetAsync(p, 0, bytes, stream), what);
+    const size_t words = bytes >> 2;
+    size_t blocks = (words / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (unsigned*)p, words);
+    return check_launch(what);
+}
+
 __global__ __launch_bounds__(256) void tg_count(int B, int N, int M, int K, int F, const int* __restrict__ nnIndex,
                                                 const int* __restrict__ nnCount, const int* __restrict__ binIndex,
                                                 int* __restrict__ deg, int* __restrict__ slotPos, int* __restrict__ binUsed)
@@ -338,7 +365,7 @@ extern "C" int sph3d_graph_transpose_count(int B, int N, int M, int K, int F, co
     if (rc || B == 0) return rc;
     hipStream_t st = as_stream(stream);
     const TgWs w = tg_ws(workspace, B, N, M, K, F);
-    rc = check_hip(hipMemsetAsync(w.deg, 0, sizeof(int) * ((size_t)B * w.L + F), st), "graph_transpose: memset");
+    rc = zero_async(w.deg, sizeof(int) * ((size_t)B * w.L + F), st, "graph_transpose: memset");
     if (rc) return rc;
     const long long total = (long long)B * M * K;
     long long blocks = (total + 255) / 256;

@@ -603,7 +603,7 @@ static int build_sphere_graph_impl(bool ocml, int B, int N, int M, int nn_sample
         fx.deg = (int*)transpose_workspace;
         fx.binUsed = fx.deg + (size_t)B * L;
         fx.slotPos = fx.binUsed + F + (size_t)B * chunks;
-        int rc = check_hip(hipMemsetAsync(fx.deg, 0, sizeof(int) * ((size_t)B * L + F), as_stream(stream)), "build_sphere_graph: memset");
+        int rc = zero_async(fx.deg, sizeof(int) * ((size_t)B * L + F), as_stream(stream), "build_sphere_graph: memset");
         if (rc) return rc;
     }
     bool fused = false;

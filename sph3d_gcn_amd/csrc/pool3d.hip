@@ -468,7 +468,7 @@ extern "C" int sph3d_max_pool3d_grad(int B, int N, int M, int C, const int* max_
     SPH3D_REQUIRE(B >= 0 && N > 0 && M >= 0 && C > 0, "MaxPool3dGrad: bad dims B=%d N=%d M=%d C=%d", B, N, M, C);
     if (B == 0) return SPH3D_OK;
     hipStream_t st = as_stream(stream);
-    int rc = check_hip(hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)B * N * C, st), "sph3d_max_pool3d_grad");
+    int rc = zero_async(grad_input, sizeof(float) * (size_t)B * N * C, st, "sph3d_max_pool3d_grad");
     if (rc) return rc;
     const long long per_b = (long long)M * C;
     if (per_b == 0) return SPH3D_OK;
