@@ -546,20 +546,21 @@ static void launch_gemm_tiles(int M, int N, int Kd, const float* A, int lda, con
     // tile choice: the largest tile that still gives every CU TWO workgroups (measured: with >= 256 tiles as the rule the
     // mid-size levels ran 50 TF, with >= 512 they run 80-90 TF: one partial wave of workgroups leaves half the CUs idle)
     auto ntiles = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    static const long long kMinTiles = getenv("SPH3D_GEMM_MINTILES") ? atoi(getenv("SPH3D_GEMM_MINTILES")) : 512;      // (experiments)
     // (BK = 32 at two workgroups per CU for the big grids: measured slower than BK = 16 at four, before and after the
     //  round-2 register fix: 0.101 vs 0.094 ms at (131072, 256 -> 128))
-    if (BKM && !(N > 64 && ntiles(128, 128) >= 512)) {
+    if (BKM && !(N > 64 && ntiles(128, 128) >= kMinTiles)) {
         // input-gradient product (W stored [n][k]) below 2 big tiles per CU: 64x64 tiles (0.071 vs 0.088 ms at
-        // (6144, 2048 -> 256) ... ) -- with >= 512 big tiles the 128x128 kernel wins since its prefetch registers stopped
+        // (6144, 2048 -> 256) ... ) -- with >= kMinTiles big tiles the 128x128 kernel wins since its prefetch registers stopped
         // going through scratch: 0.100 vs 0.106 ms at (131072, 256 -> 128), 0.089 vs 0.098 at (32768, 512 -> 256),
         // 0.062 vs 0.071 at (6144, 256 -> 2048)
         hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 64, 64, BKS, false, GUARD>), dim3(gemm_grid((M + 63) / 64, (N + 63) / 64)), dim3(256), 0, st, M,
                            N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
-    } else if (N > 64 && ntiles(128, 128) >= 512) {
+    } else if (N > 64 && ntiles(128, 128) >= kMinTiles) {
         constexpr int BKX = BKS;
         hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 128, BKX, false, GUARD>), dim3(gemm_grid((M + 127) / 128, (N + 127) / 128)), dim3(256), 0, st,
                            M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
-    } else if (N <= 64 && ntiles(128, 64) >= 512) {      // (wider outputs with fewer rows: 64x64, e.g. 0.092 vs 0.111 ms at (32768, 1024 -> 128))
+    } else if (N <= 64 && ntiles(128, 64) >= kMinTiles) {      // (wider outputs with fewer rows: 64x64, e.g. 0.092 vs 0.111 ms at (32768, 1024 -> 128))
         hipLaunchKernelGGL((gemm_f32_mfma<AK, BKM, 128, 64, BKS, false, GUARD>), dim3(gemm_grid((M + 127) / 128, (N + 63) / 64)), dim3(256), 0, st,
                            M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
     } else {
@@ -587,8 +588,9 @@ static int nn_stats_tile(int M, int N, int Kd, int& bm, int& bn)
     const bool whole = (M % 128 == 0) && (N % 64 == 0) && (N <= 64 || N % 128 == 0) && (Kd % BKS == 0) && (Kd % 4 == 0) && (N % 4 == 0);
     if (!whole) return 0;
     auto ntiles = [&](int a, int b) { return (long long)((M + a - 1) / a) * ((N + b - 1) / b); };
-    if (N > 64 && ntiles(128, 128) >= 512) { bm = 128; bn = 128; }
-    else if (ntiles(128, 64) >= 512) { bm = 128; bn = 64; }      // (N > 64 too: 32768 x 1024 -> 128 measured 81 vs 90 us with 64 x 64)
+    static const long long kMinTiles = getenv("SPH3D_GEMM_MINTILES") ? atoi(getenv("SPH3D_GEMM_MINTILES")) : 512;      // (experiments)
+    if (N > 64 && ntiles(128, 128) >= kMinTiles) { bm = 128; bn = 128; }
+    else if (ntiles(128, 64) >= kMinTiles) { bm = 128; bn = 64; }      // (N > 64 too: 32768 x 1024 -> 128 measured 81 vs 90 us with 64 x 64)
     else { bm = 64; bn = 64; }
     return 2 * (M / bm);
 }
@@ -602,7 +604,13 @@ static void tn_plan(int R, int Cin, int Cout, int& bn, int& tiles, int& nsplit, 
     // ~2 workgroups per CU in total: measured round 2 over the 13 S3DIS shapes, 512 workgroups 0.97 ms against 1.10 ms
     // with 1024 (twice the partial tiles to write and re-read, half the k-loop to amortise prologue and epilogue) and
     // 1.11 ms with 256
-    int want = (512 + tiles - 1) / tiles;      // (re-measured with the LDS-DMA kernel: 512 -> 2.25 ms over the 13 shapes, 768 2.46, 1024 2.31, 2048 2.28)
+    // SPH3D_TN_WGS: experiments.  Round 5 sweep over 256 / 384 / 512 / 768 / 1024 (tools/exp_gemm_knobs.py,
+    // profiles/r05_exp_gemm_knobs.log): 512 is the best single value (0.79 ms over the 13 shapes; per-shape optimum 0.77);
+    // only the short products with few tiles ((12288, 512 -> 256), (6144, 512 -> 512): 8 tiles, <= 12288 rows) want fewer,
+    // fatter splits: 38 / 40 us at 256 workgroups against 46 / 46
+    static const int forced = getenv("SPH3D_TN_WGS") ? atoi(getenv("SPH3D_TN_WGS")) : 0;
+    const int target = forced > 0 ? forced : ((R <= 12288 && tiles <= 8) ? 256 : 512);
+    int want = (target + tiles - 1) / tiles;   // (re-measured with the LDS-DMA kernel: 512 -> 2.25 ms over the 13 shapes, 768 2.46, 1024 2.31, 2048 2.28)
     int maxsplit = (R + 255) / 256;                   // at least 256 rows of k per split
     nsplit = want < maxsplit ? want : maxsplit;
     if (nsplit < 1) nsplit = 1;
