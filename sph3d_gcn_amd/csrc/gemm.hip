@@ -606,10 +606,10 @@ static void tn_plan(int R, int Cin, int Cout, int& bn, int& tiles, int& nsplit, 
     // 1.11 ms with 256
     // SPH3D_TN_WGS: experiments.  Round 5 sweep over 256 / 384 / 512 / 768 / 1024 (tools/exp_gemm_knobs.py,
     // profiles/r05_exp_gemm_knobs.log): 512 is the best single value (0.79 ms over the 13 shapes; per-shape optimum 0.77);
-    // only the short products with few tiles ((12288, 512 -> 256), (6144, 512 -> 512): 8 tiles, <= 12288 rows) want fewer,
+    // only the short products with few tiles ((12288, 512 -> 256), (6144, 512 -> 512): <= 16 tiles, <= 12288 rows) want fewer,
     // fatter splits: 38 / 40 us at 256 workgroups against 46 / 46
     static const int forced = getenv("SPH3D_TN_WGS") ? atoi(getenv("SPH3D_TN_WGS")) : 0;
-    const int target = forced > 0 ? forced : ((R <= 12288 && tiles <= 8) ? 256 : 512);
+    const int target = forced > 0 ? forced : ((R <= 12288 && tiles <= 16) ? 256 : 512);
     int want = (target + tiles - 1) / tiles;   // (re-measured with the LDS-DMA kernel: 512 -> 2.25 ms over the 13 shapes, 768 2.46, 1024 2.31, 2048 2.28)
     int maxsplit = (R + 255) / 256;                   // at least 256 rows of k per split
     nsplit = want < maxsplit ? want : maxsplit;
