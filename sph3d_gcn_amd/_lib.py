@@ -254,9 +254,9 @@ def scratch(nbytes, device, slot=0):
     """-> a uint8 tensor of at least nbytes on `device` for the current stream, or None for nbytes == 0"""
     if not nbytes:
         return None
-    key = (current_raw_stream(), slot)
+    key = (device.index, current_raw_stream(), slot)      # (the null stream of two devices is one handle value)
     t = _scratch.get(key)
-    if t is None or t.numel() < nbytes or t.device != device:
+    if t is None or t.numel() < nbytes:
         t = torch.empty((nbytes + nbytes // 4,), dtype=torch.uint8, device=device)
         _scratch[key] = t
     return t
