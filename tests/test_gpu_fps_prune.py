@@ -75,3 +75,12 @@ def test_pruned_fps_with_non_finite_coordinates(dev):
     with np.errstate(invalid="ignore", over="ignore"):
         want = oracle.farthest_point_sample(300, pts)
     np.testing.assert_array_equal(_fps(dev, pts, 300), want)
+
+
+def test_pruned_fps_asked_for_more_samples_than_points(dev):
+    """m > n: once every point is a sample all running distances are +0 and the reference keeps returning index 0"""
+    rng = np.random.RandomState(1)
+    pts = rng.rand(1, 2100, 3).astype(np.float32)
+    want = oracle.farthest_point_sample(2105, pts)
+    assert want[0, -5:].tolist() == [0, 0, 0, 0, 0]
+    np.testing.assert_array_equal(_fps(dev, pts, 2105), want)

@@ -56,3 +56,6 @@ if os.environ.get("PROFILE", "1") != "0":
     pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(45)
     txt = s.getvalue()
     print(txt[:9000])
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats("sph3d_gcn_amd|bench", 60)
+    print(s.getvalue()[:12000])
