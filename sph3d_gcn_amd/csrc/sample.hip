@@ -161,8 +161,11 @@ __global__ __launch_bounds__(1024) void fps_reg_kernel(int b, int n, int m,
 //     active wave (1.06 us per round at 8192 points against 1.09 for the plain kernel); 4 or 8 waves with 32 / 16 points per
 //     lane (1.53 / 1.15: fewer waves hide less of each other's latency); updating ALL slots of an active wave in straight-line
 //     code instead of branching per slot (0.95, 1.10 with the blobs dealt in turn); a wave owning P CONSECUTIVE blobs (0.97).
-//     This form (with the atomic-max exchange below): 0.83 us per round at 8192 points (plain 1.10), 1.03 at 10 000 (1.39),
-//     0.71 at 4096 (0.77), 0.70 at 2500 (0.78); at 2048 the plain kernel stays ahead (0.62 against 0.70);
+//     This form (with the atomic-max exchange and the winning lane publishing its own coordinates, below): 0.82 us per round at
+//     8192 points (plain 1.09), 0.87 at 10 000 (1.39), 0.70 at 4096 (0.77), 0.69 at 2500 (0.77); at 2048 the plain kernel stays
+//     ahead (0.61 against 0.69).  Two diagnostic builds (-DSPH3D_FPS_EXP) bound what is left: a round WITHOUT any update (box
+//     test, publish, barrier, exchange) takes 0.24 us; the rest is the dependent path of the waves with work — above all of the
+//     wave that owned the winner: its candidate just became the sample, so it updates, rescans and re-elects every round;
 //   * the reference's tie-break (tf_sample_gpu.cu:49,56-66: larger distance, then lower thread id k mod 1024, then lower k)
 //     no longer follows from the thread mapping — the points are permuted — so it is carried explicitly: a point's key is
 //     (bits of td) << 32 | sec(k), sec(k) = (1023 - k mod 1024) << 8 | (255 - k div 1024); the largest key wins and the
@@ -198,30 +201,6 @@ __device__ __forceinline__ unsigned morton4(unsigned v)      // 4 bits -> every 
 }
 
 typedef unsigned long long u64;
-
-// The candidate of a wave: coordinates and sec of point p of lane wl, p and wl wave-uniform.  A chain of uniform branches with
-// the four v_readlane inside (the empty asm keeps the compiler from turning the chain into a dynamically indexed private array —
-// which it then moves to LDS, 66 KB of it — or into P selects per value).
-template <int I, int P>
-struct FpsPick {
-    static __device__ __forceinline__ void get(int p, int wl, const float (&px)[P], const float (&py)[P], const float (&pz)[P],
-                                               const u64 (&key)[P], float& x, float& y, float& z, unsigned& sc)
-    {
-        if (p == I || I == P - 1) {
-            int a = __builtin_amdgcn_readlane(__float_as_int(px[I]), wl);
-            int b = __builtin_amdgcn_readlane(__float_as_int(py[I]), wl);
-            int c = __builtin_amdgcn_readlane(__float_as_int(pz[I]), wl);
-            int d = __builtin_amdgcn_readlane((int)(unsigned)key[I], wl);
-            asm volatile("" : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
-            x = __int_as_float(a);
-            y = __int_as_float(b);
-            z = __int_as_float(c);
-            sc = (unsigned)d;
-        } else if constexpr (I + 1 < P) {
-            FpsPick<I + 1, P>::get(p, wl, px, py, pz, key, x, y, z, sc);
-        }
-    }
-};
 
 struct __attribute__((aligned(16))) FpsSlotP {
     unsigned vbits;        // bits of the candidate's running distance (>= +0: ordered as unsigned)
@@ -366,15 +345,16 @@ __global__ __launch_bounds__(64 * NW) void fps_prune_kernel(int b, int n, int m,
         // the lane's cached arg-max (key, slot)
         float g = __builtin_inff();
         unsigned c_vb = 0u, c_sec = 0u;
-        float c_x = 0.f, c_y = 0.f, c_z = 0.f;
+        int c_wl = 0, dirty = 0;
         u64 kb = 0ull;
         int bp = 0;
+        float bx = 0.f, by = 0.f, bz = 0.f;
         int c3 = 1;                                            // j mod 3
         if (t < 3) cell[t] = 0ull;
         __syncthreads();
 
 #ifdef SPH3D_FPS_PROF
-        unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // own work (active / idle rounds), their counts, publish + barrier, post, rescans, slots updated
+        unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // own work (active / idle rounds), their counts, publish + barrier, post, rescans, their own cycles
 #endif
         for (int j = 1; j < m; j++) {
             const unsigned long long tk0 = FPS_CLK(); (void)tk0;
@@ -384,7 +364,10 @@ __global__ __launch_bounds__(64 * NW) void fps_prune_kernel(int b, int n, int m,
             const float ex = qx - x1, ey = qy - y1, ez = qz - z1;
             const float dbox = (ex * ex + ey * ey) + ez * ez;
             const bool need = lane < P && !(dbox >= g);        // NaN on either side: update
-            const unsigned mask = (unsigned)__ballot(need);
+#ifndef SPH3D_FPS_EXP
+#define SPH3D_FPS_EXP 0        // diagnostic builds only (WRONG samples): 1 = never rescan after round 1, 2 = never update after round 1
+#endif
+            const unsigned mask = (SPH3D_FPS_EXP == 2 && j > 1) ? 0u : (unsigned)__ballot(need);
             u64 stale = j == 1 ? ~0ull : 0ull;                 // lanes whose cached arg-max was lowered this round
             if (mask != 0u) {
 #pragma unroll
@@ -403,13 +386,15 @@ __global__ __launch_bounds__(64 * NW) void fps_prune_kernel(int b, int n, int m,
                     }
                 }
             }
+            if (SPH3D_FPS_EXP == 1 && j > 1) stale = 0ull;
             if (stale != 0ull) {
                 // ---- some lane's arg-max moved: every lane rescans its points (a tournament: log2 P dependent steps), the
                 // wave re-elects its candidate ----
                 u64 tk[P];
                 int tb[P];
+                float tx[P], ty[P], tz[P];
 #pragma unroll
-                for (int p = 0; p < P; p++) { tk[p] = key[p]; tb[p] = p; }
+                for (int p = 0; p < P; p++) { tk[p] = key[p]; tb[p] = p; tx[p] = px[p]; ty[p] = py[p]; tz[p] = pz[p]; }
 #pragma unroll
                 for (int st = 1; st < P; st <<= 1)
 #pragma unroll
@@ -417,21 +402,29 @@ __global__ __launch_bounds__(64 * NW) void fps_prune_kernel(int b, int n, int m,
                         const bool gt = tk[q + st] > tk[q];
                         tk[q] = gt ? tk[q + st] : tk[q];
                         tb[q] = gt ? tb[q + st] : tb[q];
+                        tx[q] = gt ? tx[q + st] : tx[q];
+                        ty[q] = gt ? ty[q + st] : ty[q];
+                        tz[q] = gt ? tz[q + st] : tz[q];
                     }
                 kb = tk[0];
                 bp = tb[0];
+                bx = tx[0];                                    // the lane's best point travels with its key: the winning lane
+                by = ty[0];                                    // publishes its coordinates from its own registers (below)
+                bz = tz[0];
                 const unsigned kh = (unsigned)(kb >> 32);
                 const unsigned wmb = wave_max_u32(kh);
                 const u64 tie = __ballot(kh == wmb);
-                int wl = (int)__builtin_ctzll(tie);
+                c_wl = (int)__builtin_ctzll(tie);
                 if (tie & (tie - 1ull)) {                      // several lanes at the maximum: the largest sec among them
                     const unsigned ls = kh == wmb ? (unsigned)kb : 0u;
                     const unsigned ws = wave_max_u32(ls);
-                    wl = (int)__builtin_ctzll(__ballot(kh == wmb && ls == ws));
+                    c_wl = (int)__builtin_ctzll(__ballot(kh == wmb && ls == ws));
+                    c_sec = ws;
+                } else {
+                    c_sec = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)kb, c_wl);
                 }
-                const int pstar = __builtin_amdgcn_readlane(bp, wl);
-                FpsPick<0, P>::get(pstar, wl, px, py, pz, key, c_x, c_y, c_z, c_sec);
                 c_vb = wmb;
+                dirty = 2;                                     // both parities of the wave's slot take the new coordinates
             }
             const unsigned long long tk1 = FPS_CLK(); (void)tk1;
             // ---- exchange: every wave publishes its candidate's coordinates and raises the round's cell to its key with ONE LDS
@@ -445,14 +438,21 @@ __global__ __launch_bounds__(64 * NW) void fps_prune_kernel(int b, int n, int m,
             // atomics are long done when the waves with work arrive.  Cells rotate over three rounds:
             // the one of round j + 2 is cleared after barrier j, when round j - 1's readers are done and before barrier j + 1 lets
             // round j + 2's writers through.
+            // The coordinates never pass through scalar registers: after a re-election the winning LANE writes them from its own
+            // registers into the wave's slot of this round's parity and of the next round's (a first version read the lane's slot index
+            // back, branched to the matching registers and read-laned four values: ~300 of a rescan round's ~1250 cycles).
             const int buf = j & 1;
-            if (lane == 0) {
-                FpsSlotP sl;
-                sl.vbits = c_vb; sl.x = c_x; sl.y = c_y; sl.z = c_z;
-                slots[buf][wave] = sl;
+            if (dirty > 0) {                                   // wave-uniform
+                if (lane == c_wl) {
+                    FpsSlotP sl;
+                    sl.vbits = c_vb; sl.x = bx; sl.y = by; sl.z = bz;
+                    slots[buf][wave] = sl;
+                }
+                dirty--;
+            }
+            if (lane == 0)
                 __hip_atomic_fetch_max(&cell[c3], ((u64)c_vb << 32) | ((u64)c_sec << 4) | (u64)wave, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
             __syncthreads();
             const unsigned long long tk2 = FPS_CLK(); (void)tk2;
             const u64 win = cell[c3];                              // the same address in every lane: a broadcast read
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(64 * NW) void fps_prune_kernel(int b, int n, int m,
                 pf[4] += tk2 - tk1;
                 pf[5] += tk3 - tk2;
                 pf[6] += stale != 0ull ? 1 : 0;
-                pf[7] += (unsigned long long)__popc(mask);
+                pf[7] += (stale != 0ull) ? (tk1 - tk0) : 0ull;       // own cycles of the rounds with a rescan
             }
 #endif
         }

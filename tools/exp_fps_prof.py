@@ -19,12 +19,14 @@ for N, m in ((8192, 2048), (2048, 768)):
     a = np.array(list(out), dtype=np.float64).reshape(16, 8)
     us = e0.elapsed_time(e1) * 1e3
     print("N %d -> %d: %.1f us, %.3f us/round" % (N, m, us, us / (m - 1)))
-    print(" wave | active rounds: n, own cycles | idle rounds: n, own cycles | publish+barrier | post | rescans | slots updated")
+    print(" wave | active rounds: n, own cycles (with a rescan: n, cycles; without: cycles) | idle rounds: n, own cycles | publish+barrier | post")
     for w in range(16):
         r = a[w]
         if r[2] + r[3] == 0:
             continue
-        print("  %2d  | %5d %7.0f | %5d %7.0f | %7.0f | %6.0f | %5d | %6d" % (w, r[2], r[0] / max(r[2], 1), r[3], r[1] / max(r[3], 1),
-                                                                            r[4] / (r[2] + r[3]), r[5] / (r[2] + r[3]), r[6], r[7]))
+        nores = max(r[2] - r[6], 1)
+        print("  %2d  | %5d %7.0f (%5d %7.0f; %7.0f) | %5d %7.0f | %7.0f | %6.0f" % (
+            w, r[2], r[0] / max(r[2], 1), r[6], r[7] / max(r[6], 1), (r[0] - r[7]) / nores, r[3], r[1] / max(r[3], 1),
+            r[4] / (r[2] + r[3]), r[5] / (r[2] + r[3])))
     tot = a[:, 0] + a[:, 1] + a[:, 4] + a[:, 5]
     print(" cycles per round (wave 0): %.0f  -> clock %.2f GHz if the loop is the whole kernel" % (tot[0] / (m - 1), tot[0] / (m - 1) / (us / (m - 1)) / 1e3))
