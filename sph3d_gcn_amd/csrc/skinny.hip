@@ -53,16 +53,19 @@ __global__ __launch_bounds__(256) void skinny_nn_kernel(int R, int K1, int K2, i
         for (int t = 0; t < kSkKT; t++) {
             if (t < kt) a[t] = *reinterpret_cast<const sk_f32x4*>(t < kt1 ? p1 + 16 * t : p2 + 16 * (t - kt1));   // wave-uniform selects
         }
-        sk_f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        // four independent accumulation chains (one per k-slot of the 16-byte load): 64 dependent MFMAs in ONE chain left the
+        // wave waiting for its own previous result
+        sk_f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0, d2 = d0, d3 = d0;
 #pragma unroll
         for (int t = 0; t < kSkKT; t++) {
             if (t < kt) {
-                d = sk_mfma(a[t].x, wreg[t][0], d);
-                d = sk_mfma(a[t].y, wreg[t][1], d);
-                d = sk_mfma(a[t].z, wreg[t][2], d);
-                d = sk_mfma(a[t].w, wreg[t][3], d);
+                d0 = sk_mfma(a[t].x, wreg[t][0], d0);
+                d1 = sk_mfma(a[t].y, wreg[t][1], d1);
+                d2 = sk_mfma(a[t].z, wreg[t][2], d2);
+                d3 = sk_mfma(a[t].w, wreg[t][3], d3);
             }
         }
+        const sk_f32x4 d = (d0 + d1) + (d2 + d3);
         // D: lane holds rows 4*(lane/16) + r, r < 4, of column lane % 16
         if (i16 < N) {
 #pragma unroll
