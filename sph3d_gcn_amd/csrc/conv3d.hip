@@ -382,8 +382,11 @@ __global__ __launch_bounds__(256) void dwconv_fwd_generic(
 constexpr int kBwdTWaves = 4;
 constexpr int kBwdTPointsPerWG = 64;     // measured: 256 -> 1.90 ms, 128 -> 1.15, 64 -> 0.90, 32 -> 0.91, 16 -> 1.22 (tail / balance vs per-block setup)
 
-#ifndef SPH3D_BWD_NL
-#define SPH3D_BWD_NL 2      // measured at C = 64, r = 2, level 0: 2 loads (4 edges) per batch 0.532 ms, 4 loads 0.631, one row per load 0.589
+#ifndef SPH3D_BWD_NL2
+#define SPH3D_BWD_NL2 3     // wave loads per batch of the half-wave form (2 edges per load)
+#endif
+#ifndef SPH3D_BWD_NL4
+#define SPH3D_BWD_NL4 2     // ... of the quarter-wave form (4 edges per load)
 #endif
 // PARTS = 2 (CR <= 128, V == 4): a grad_out row is at most 32 lanes wide, so the two halves of the wave take ALTERNATE edges of
 // a segment (one wave load = two rows) and keep separate partial sums, added across the halves once per source
@@ -540,29 +543,35 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
                     if (HALF) {
                         // the two half-waves take alternate edges: lane-half h reads edge e + 2u + h of the chunk through
                         // ds_bpermute (lane number modulo 64, scales masked to the segment: see the full-wave branch)
-                        constexpr int NL = SPH3D_BWD_NL;          // wave loads per batch = 2 * NL edges
+                        constexpr int NL = PARTS == 2 ? SPH3D_BWD_NL2 : SPH3D_BWD_NL4;          // wave loads per batch = PARTS * NL edges
                         const float svh = ((unsigned)(lane - e0) < (unsigned)(e1 - e0)) ? sv : 0.f;
                         // (exact-count last batches, which pay in the full-wave branch, measured no gain here: 0.305 vs 0.319 ms)
+                        // a batch that runs past lane 63 wraps (ds_bpermute takes the lane modulo 64) onto lanes 0.. of the chunk, which
+                        // belong to the segment when it is (nearly) the whole chunk: impossible while the batch divides 64 (4 and 8
+                        // edges), masked by the edge number in that one batch otherwise (6 edges: segments of 61+ in-edges)
+#define SPH3D_BWD_HALF_BATCH(WRAPS)                                                                                  \
+    {                                                                                                                \
+        const int a4 = ((e + half) << 2);                                                                            \
+        unsigned ko[NL];                                                                                             \
+        float sc[NL];                                                                                                \
+        _Pragma("unroll") for (int u = 0; u < NL; u++) {                                                             \
+            ko[u] = (unsigned)__builtin_amdgcn_ds_bpermute(a4 + 4 * PARTS * u, (int)kel);                            \
+            sc[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(a4 + 4 * PARTS * u, __float_as_int(svh)));           \
+            if (WRAPS) sc[u] = (e + half + PARTS * u) < 64 ? sc[u] : 0.f;                                            \
+        }                                                                                                            \
+        float g[NL][V];                                                                                              \
+        _Pragma("unroll") for (int u = 0; u < NL; u++) {                                                             \
+            const float4 t = *reinterpret_cast<const float4*>(&gou[ko[u] + cla]);                                    \
+            g[u][0] = t.x; g[u][1 % V] = t.y; g[u][2 % V] = t.z; g[u][3 % V] = t.w;                                  \
+        }                                                                                                            \
+        _Pragma("unroll") for (int u = 0; u < NL; u++)                                                               \
+            _Pragma("unroll") for (int v = 0; v < V; v++) sg[v] = fmaf(g[u][v], sc[u], sg[v]);                       \
+    }
                         for (int e = e0; e < e1; e += PARTS * NL) {
-                            const int a4 = ((e + half) << 2);
-                            unsigned ko[NL];
-                            float sc[NL];
-#pragma unroll
-                            for (int u = 0; u < NL; u++) {
-                                ko[u] = (unsigned)__builtin_amdgcn_ds_bpermute(a4 + 4 * PARTS * u, (int)kel);
-                                sc[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(a4 + 4 * PARTS * u, __float_as_int(svh)));
-                            }
-                            float g[NL][V];
-#pragma unroll
-                            for (int u = 0; u < NL; u++) {
-                                const float4 t = *reinterpret_cast<const float4*>(&gou[ko[u] + cla]);
-                                g[u][0] = t.x; g[u][1 % V] = t.y; g[u][2 % V] = t.z; g[u][3 % V] = t.w;
-                            }
-#pragma unroll
-                            for (int u = 0; u < NL; u++)
-#pragma unroll
-                                for (int v = 0; v < V; v++) sg[v] = fmaf(g[u][v], sc[u], sg[v]);
+                            if ((64 % (PARTS * NL)) != 0 && e + PARTS * NL > 64) SPH3D_BWD_HALF_BATCH(true)
+                            else SPH3D_BWD_HALF_BATCH(false)
                         }
+#undef SPH3D_BWD_HALF_BATCH
                     } else {
                     // scales of THIS segment's lanes, zero elsewhere: a batch may then run past the segment end (and, as
                     // v_readlane takes the lane number modulo 64, wrap to lanes below e0) without clamps or selects:

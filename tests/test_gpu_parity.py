@@ -253,6 +253,37 @@ def test_conv_grad_all_bins_and_compact_bins(dev, C, r, nbins):
     assert (_n(gf)[unused] == 0).all()                            # bins that never occur get an exact zero gradient
 
 
+@pytest.mark.parametrize("C,r", [(36, 2), (64, 2), (64, 1), (32, 1), (128, 2), (16, 1)])
+@pytest.mark.parametrize("hub_edges", [61, 64, 65, 127, 200])
+def test_conv_grad_hub_source_with_one_long_segment(dev, C, r, hub_edges):
+    """A source point that is the neighbour of many queries IN ONE BIN: its (source, bin) segment fills whole 64-edge chunks
+    of the transposed graph.  The half- and quarter-wave gradient forms consume a segment in batches of 6 or 8 edges whose
+    lane numbers wrap modulo 64 at the end of a chunk; a batch size that does not divide 64 once counted the first edges
+    of such a chunk twice (segments of 61+ edges: found by the ModelNet full-size test only)."""
+    B, N, K = 2, 256, 8
+    rng = np.random.RandomState(hub_edges * 7 + C + r)
+    cnt = rng.randint(1, K + 1, size=(B, N)).astype(np.int32)
+    idx = np.zeros((B, N, K), np.int32)
+    filt = np.zeros((B, N, K), np.int32)
+    for b in range(B):
+        for m in range(N):
+            c = int(cnt[b, m])
+            idx[b, m, :c] = np.sort(rng.permutation(np.arange(1, N))[:c])
+            filt[b, m, :c] = rng.randint(0, 33, size=c)
+        hub = rng.permutation(N)[:hub_edges]
+        idx[b, hub, 0] = 0                                 # point 0 first (ascending order holds), always in bin 5
+        filt[b, hub, 0] = 5
+    x = rng.randn(B, N, C).astype(np.float32)
+    w = rng.randn(33, C, r).astype(np.float32)
+    go = rng.randn(B, N, C * r).astype(np.float32)
+    gi_o, gf_o = oracle.depthwise_conv3d_grad(x, w, go, idx, cnt, filt)
+    gi, gf = tf_conv3d.depthwise_conv3d_grad(_t(x, dev), _t(w, dev), _t(go, dev), _t(idx, dev), _t(cnt, dev), _t(filt, dev))
+    s_i = max(1.0, float(np.abs(gi_o).max()))
+    np.testing.assert_allclose(_n(gi) / s_i, gi_o / s_i, **TOL)
+    s_ = max(1.0, float(np.abs(gf_o).max()))
+    np.testing.assert_allclose(_n(gf) / s_, gf_o / s_, **TOL)
+
+
 # (B, N, M, C, r, K)
 CONV_CASES = [(2, 200, 100, 8, 2, 16), (1, 64, 64, 3, 1, 8), (2, 300, 300, 35, 2, 32), (2, 256, 256, 67, 1, 64),
               (2, 500, 500, 64, 2, 64), (1, 300, 150, 128, 2, 64), (1, 128, 128, 1024, 2, 64), (2, 200, 200, 131, 1, 16),
