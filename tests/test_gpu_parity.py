@@ -381,6 +381,60 @@ def test_unpooling(dev, case):
                                    _n(wi), **TOL)
 
 
+@pytest.mark.parametrize("C", [8, 64, 67, 128, 256])
+@pytest.mark.parametrize("hub_edges", [63, 64, 65, 130, 300])
+def test_pool_unpool_gradients_hub_source(dev, C, hub_edges):
+    """The pooling / un-pooling gradients gather over the transposed graph, 64 in-edges of a source at a time: one source point
+    listed by `hub_edges` queries (whole chunks, a chunk + 1, several chunks) next to ordinary sparse rows."""
+    from sph3d_gcn_amd import _tgraph
+    B, N, M, K = 2, 320, 300, 6
+    rng = np.random.RandomState(hub_edges * 11 + C)
+    cnt = rng.randint(1, K + 1, size=(B, M)).astype(np.int32)
+    idx = np.zeros((B, M, K), np.int32)
+    for b in range(B):
+        for m in range(M):
+            c = int(cnt[b, m])
+            idx[b, m, :c] = np.sort(rng.permutation(np.arange(1, N))[:c])
+        idx[b, rng.permutation(M)[:hub_edges], 0] = 0          # the hub: point 0, first in its rows (rows stay ascending and unique)
+    x = rng.randn(B, N, C).astype(np.float32)
+    x[:, ::3] = np.round(x[:, ::3])
+    go = rng.randn(B, M, C).astype(np.float32)
+    it, ct = _t(idx, dev), _t(cnt, dev)
+    # max pool: the gather form of the gradient (a transposed graph built ahead with the unique-rows promise) and the plain one
+    out_o, mi_o = oracle.max_pool3d(x, idx, cnt)
+    want = oracle.max_pool3d_grad(x, go, mi_o)
+    for ahead in (False, True):
+        _tgraph.clear()
+        if ahead:
+            _tgraph.transpose(it, ct, N, unique_rows=True)
+        xt = _t(x, dev).requires_grad_(True)
+        out, mi = tf_pool3d.max_pool3d(xt, it, ct)
+        np.testing.assert_array_equal(_n(mi), mi_o)
+        out.backward(_t(go, dev))
+        s_ = max(1.0, float(np.abs(want).max()))               # (the hub's gradient is a sum of up to 300 terms)
+        np.testing.assert_allclose(_n(xt.grad) / s_, want / s_, **TOL)
+    xt2 = _t(x, dev).requires_grad_(True)
+    tf_pool3d.avg_pool3d(xt2, it, ct).backward(_t(go, dev))
+    ref = oracle.avg_pool3d_grad(x, go, idx, cnt)
+    s_ = max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(_n(xt2.grad) / s_, ref / s_, **TOL)
+    # un-pooling over the same rows: database = the N points (features [B, N, C]), queries = the M rows
+    w = rng.rand(B, M, K).astype(np.float32)
+    w[np.arange(K)[None, None, :] >= cnt[:, :, None]] = 0
+    w /= w.sum(-1, keepdims=True)
+    ft = _t(x, dev).requires_grad_(True)
+    tf_unpool3d.mean_interpolate(ft, it, ct).backward(_t(go, dev))
+    ref = oracle.mean_interpolate_grad(x, go, idx, cnt)
+    s_ = max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(_n(ft.grad) / s_, ref / s_, **TOL)
+    ft2 = _t(x, dev).requires_grad_(True)
+    tf_unpool3d.weighted_interpolate(ft2, _t(w, dev), it, ct).backward(_t(go, dev))
+    ref = oracle.weighted_interpolate_grad(x, go, w, idx, cnt)
+    s_ = max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(_n(ft2.grad) / s_, ref / s_, **TOL)
+    _tgraph.clear()
+
+
 def test_device_scalar_math_matches_host_bitwise(dev):
     """sqrt / divide are correctly rounded on device and sph3d_atan2f is bit-identical host vs device."""
     import ctypes
