@@ -218,7 +218,11 @@ class FlatGradAllReduce:
             got.clear()
         self._armed = True
         try:
-            grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+            # backward on the ISSUING thread: handing the pass to the engine's device thread and waking up again when it is done
+            # costs 0.1-1.3 ms per step of host time depending on the box (tools/exp_host_floor.py: 7.85 -> 6.56 ms to issue a
+            # one-block step), and the ~400 launches of a step are what a rank's host has to keep ahead of its GPU
+            with torch.autograd.set_multithreading_enabled(os.environ.get("SPH3D_AUTOGRAD_THREAD", "0") == "1"):
+                grads = torch.autograd.grad(loss, self.params, allow_unused=True)
         finally:
             self._armed = False
         for bi, (i0, i1, f0, f1) in enumerate(self.buckets):       # buckets with parameters the loss does not depend on
