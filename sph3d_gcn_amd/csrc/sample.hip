@@ -18,6 +18,7 @@
 // Clouds larger than 1024 * 24 points fall back to a kernel that keeps the running distance in a
 // caller-provided workspace (the reference's `temp`) and re-reads xyz from L2.
 // -ffp-contract=off: d = (dx*dx + dy*dy) + dz*dz must round like the oracle.
+#include <atomic>
 #include <cstdlib>
 #include "common.hpp"
 
@@ -585,8 +586,14 @@ __global__ __launch_bounds__(1024) void fps_big_kernel(int b, int n, int m, cons
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kCoopP = 4;                  // points per thread
 constexpr int kCoopPts = kRefBlock * kCoopP;
+#ifndef SPH3D_FPS_COOP_ERRPOLL
+#define SPH3D_FPS_COOP_ERRPOLL 0
+#endif
+#ifndef SPH3D_FPS_COOP_SLOAD
+#define SPH3D_FPS_COOP_SLOAD 1
+#endif
 
-__global__ __launch_bounds__(1024) void fps_coop_kernel(int n, int m, int G, const float* __restrict__ dataset,
+__global__ __launch_bounds__(1024) void fps_coop_kernel(int b, int xcd_local, int n, int m, int G, const float* __restrict__ dataset,
                                                         unsigned long long* __restrict__ slots, int* __restrict__ err,
                                                         int* __restrict__ idxs)
 {
@@ -596,7 +603,18 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(int n, int m, int G, con
     const int t = (int)threadIdx.x;
     const int lane = t & 63;
     const int wave = uniform(t >> 6);
-    const int i = (int)blockIdx.x / G, g = (int)blockIdx.x % G;
+    // xcd_local: the G workgroups of a cloud on ONE XCD (block b runs on XCD b % 8 — observed, used for speed only: an exchange
+    // inside one L2 is 0.1-0.3 us shorter than across the fabric); the grid is 8 x as large and the surplus workgroups leave
+    int i, g;
+    if (xcd_local) {
+        const int slot = (int)blockIdx.x >> 3;
+        i = (slot / G) * 8 + (((int)blockIdx.x + 9 - xcd_local) & 7);             // xcd_local - 1 = the XCD of cloud 0 (rotates per launch)
+        g = slot % G;
+        if (i >= b) return;
+    } else {
+        i = (int)blockIdx.x / G;
+        g = (int)blockIdx.x % G;
+    }
     const float* pts = dataset + (size_t)i * n * 3;
     unsigned long long* myslots = slots + (size_t)i * 2 * G;
     float px[kCoopP], py[kCoopP], pz[kCoopP], td[kCoopP];
@@ -646,6 +664,10 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(int n, int m, int G, con
                                             ((unsigned long long)(255 - q) << 14) | (unsigned long long)(j & 0x3fff);
             if (lane == 0) __hip_atomic_store(&myslots[buf * G + g], gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // ... meets the other workgroups' candidates
+            // (round 5, measured and dropped, 65 536 points, us per round: the candidates' coordinates as three more tagged granules
+            //  per workgroup, one 64-lane sweep — 2.18 against 1.96, and 2.55 with every wave polling for itself instead of wave 0 +
+            //  barrier: the poll's price is the number of 8-byte requests in the polling CU's memory queue; a lane fetching its
+            //  candidate's point as soon as its granule is in, under the poll for the others: 1.97 against 1.72)
             const int gl = lane < G ? lane : 0;
             unsigned long long v = 0ull;
             int spins = 0;
@@ -653,38 +675,43 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(int n, int m, int G, con
                 v = __hip_atomic_load(&myslots[buf * G + gl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const bool ok = (int)(v & 0x3fffull) == (j & 0x3fff);
                 if (__ballot(ok) == ~0ull) break;
-                if (++spins > (1 << 22) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                // (the error word is looked at every 16th poll only: a second fabric round trip in EVERY failed poll doubled the
+                //  period of the poll, i.e. the mean delay between a granule's arrival and its detection)
+                if (++spins > (1 << 22) || ((spins & 15) == SPH3D_FPS_COOP_ERRPOLL && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                     if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     v = ~0ull;                                                   // poison: the round loop ends below
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
-            unsigned long long key = v >> 14;
-            if (v == ~0ull) key = ~0ull;
-#pragma unroll
-            for (int s2 = 1; s2 < 64; s2 <<= 1) {
-                const unsigned long long o = shfl_xor_u64(key, s2);
-                key = o > key ? o : key;
+            // the winner: max of the granules' upper 50 bits (value, then 1023 - t, then 255 - (k >> 10)) in two 32-bit DPP steps
+            // (a 64-bit butterfly is twelve dependent ds_bpermute)
+            const bool poisoned = __ballot(v == ~0ull) != 0ull;
+            const unsigned hi = lane < G ? (unsigned)(v >> 32) : 0u;
+            const unsigned hmax = wave_max_u32(hi);
+            const unsigned lo = (lane < G && hi == hmax) ? (unsigned)((v >> 14) & 0x3ffffull) + 1u : 0u;
+            const unsigned lmax = wave_max_u32(lo);
+            int k = -1;
+            if (!poisoned) {
+                const unsigned low18 = lmax - 1u;
+                const int kt = 1023 - (int)((low18 >> 8) & 0x3ffu);
+                const int kq = 255 - (int)(low18 & 0xffu);
+                k = kq * kRefBlock + kt;
+                // best < 0 everywhere (no point left: cannot happen for m <= n) -> index 0 like the reference's idle threads
+                if (hmax == order_bits(-1.f)) k = 0;
+                if (k >= n) k = 0;
             }
             if (lane == 0) {
-                int k = -1;
-                if (key != ~0ull) {
-                    const int kt = 1023 - (int)((key >> 8) & 0x3ffull);
-                    const int kq = 255 - (int)(key & 0xffull);
-                    const float bv = __uint_as_float(0);
-                    (void)bv;
-                    k = kq * kRefBlock + kt;
-                    // best < 0 everywhere (no point left: cannot happen for m <= n) -> index 0 like the reference's idle threads
-                    if ((unsigned)(key >> 18) == order_bits(-1.f)) k = 0;
-                    if (k >= n) k = 0;
-                }
                 win_k[buf] = k;
                 if (g == 0 && k >= 0) idxs[(size_t)i * m + j] = k;
             }
         }
         __syncthreads();
+#if SPH3D_FPS_COOP_SLOAD
+        const int k = uniform(win_k[buf]);                                       // scalar loads of the winner's point (read-only cloud)
+#else
         const int k = win_k[buf];
+#endif
         if (k < 0) break;                                                        // time-out: give up (err is set)
         x1 = pts[(size_t)k * 3];
         y1 = pts[(size_t)k * 3 + 1];
@@ -793,7 +820,14 @@ extern "C" int sph3d_farthest_point_sample(int b, int n, int m, const float* inp
                 if (rc) return rc;
             }
             unsigned long long* slots = (unsigned long long*)((char*)workspace + 256);
-            hipLaunchKernelGGL(fps_coop_kernel, dim3(b * G), dim3(kRefBlock), 0, st, n, m, G, inp, slots, err, out);
+            // all workgroups of a cloud on one XCD while they take at most half of its 32 CUs (one 1024-thread workgroup per CU)
+            static const int xcd_env = getenv("SPH3D_FPS_COOP_XCD") ? atoi(getenv("SPH3D_FPS_COOP_XCD")) : 1;      // (experiments)
+            const int rounds8 = (b + 7) / 8;
+            // (launches rotate over the XCDs: two sampling streams' kernels of one-cloud batches would share XCD 0 otherwise)
+            static std::atomic<unsigned> rotate{0};
+            const int xcd_local = (xcd_env != 0 && rounds8 * G <= 16) ? 1 + (int)(rotate.fetch_add(1, std::memory_order_relaxed) & 7u) : 0;      // (32 per XCD measured slower than spread: 2.88 vs 2.46 us per round at 131 072 points)
+            const unsigned nblk = xcd_local ? (unsigned)(8 * rounds8 * G) : (unsigned)(b * G);
+            hipLaunchKernelGGL(fps_coop_kernel, dim3(nblk), dim3(kRefBlock), 0, st, b, xcd_local, n, m, G, inp, slots, err, out);
             rc = check_launch("sph3d_farthest_point_sample (co-operative pass)");
             if (rc) return rc;
             // repair pass: returns at once unless the co-operative pass timed out (then every cloud is resampled, bit-exactly)
