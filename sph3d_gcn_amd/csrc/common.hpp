@@ -67,14 +67,24 @@ __device__ __forceinline__ float uniformf(float v)
 // XCD-affine work decode.  Workgroup `bid` runs on XCD (bid % 8) (observed placement, used for
 // L2 locality only, never for correctness).  Clouds are dealt to XCDs round-robin so that all
 // workgroups of one cloud share one L2: returns (cloud, part) for this block or cloud = -1.
+// Batches of fewer than five clouds would leave XCDs without work that way (ONE cloud: the whole launch on 32 of the 256 CUs —
+// the ScanNet-shape line until round 5): such a batch gives every cloud 2, 4 or 8 XCDs and deals the cloud's parts over them.
+__host__ __device__ __forceinline__ int xcd_spread_log2(int B) { return B >= 5 ? 0 : (B >= 3 ? 1 : (B == 2 ? 2 : 3)); }
 __device__ __forceinline__ void xcd_decode(int bid, int B, int parts, int& cloud, int& part)
 {
+    const int ls = xcd_spread_log2(B), s = 1 << ls;       // XCDs per cloud
     const int x = bid & 7;
     const int y = bid >> 3;
-    cloud = x + 8 * (y / parts);
-    part = y % parts;
-    if (cloud >= B) cloud = -1;
+    const int pps = (parts + s - 1) >> ls;                // parts per XCD of a cloud
+    const int row = y / pps;
+    cloud = (x >> ls) + (8 >> ls) * row;
+    part = (x & (s - 1)) + s * (y - row * pps);
+    if (cloud >= B || part >= parts) cloud = -1;
 }
-static inline int xcd_grid(int B, int parts) { return 8 * ((B + 7) / 8) * parts; }
+static inline int xcd_grid(int B, int parts)
+{
+    const int ls = xcd_spread_log2(B), s = 1 << ls, cpr = 8 >> ls;
+    return 8 * ((B + cpr - 1) / cpr) * ((parts + s - 1) >> ls);
+}
 
 }  // namespace sph3d
