@@ -453,7 +453,7 @@ def eval_main(args, rank, world, dev, pinned_cpus):
                                       "blocks/GPU, graph build + forward; separable layers as one kernel where that is the faster "
                                       "form (FUSE_SEPARABLE_INFERENCE = %r)" % (BLOCKS_PER_GPU, fuse_mode),
                           "global_batch": world * BLOCKS_PER_GPU, "points_per_block": NUM_POINT, "atan2": args.atan2,
-                          "sampling_streams": s3dis_net.SAMPLING_STREAMS,
+                          "sampling_streams": s3dis_net.SAMPLING_STREAMS, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
                           "parallelism": "dp%d (replicas, no collective)" % world, "cpus_per_rank": pinned_cpus},
                "ms_per_step_layer_by_layer": round(t_unfused * 1e3, 3),
                "families_ms_per_step": families, "kernels": kernels, "roofline": None, "cpu_baseline": None}
@@ -470,7 +470,7 @@ def secondary_main(args, rank, world, dev, pinned_cpus):
     from sph3d_gcn_amd.harness import modelnet_net, shapenet_net
     name = args.config
     rng = np.random.RandomState(17 + rank)
-    s3dis_net.SAMPLING_STREAMS = args.sampling_streams or (2 if name == "scannet" else 1)
+    s3dis_net.SAMPLING_STREAMS = args.sampling_streams or (4 if name == "scannet" else 1)
     if name == "modelnet":
         per_gpu, npts = 32, 10000
         cfg = modelnet_net.modelnet_config(npts)
@@ -569,7 +569,7 @@ def secondary_main(args, rank, world, dev, pinned_cpus):
                           "parallelism": "dp%d (one cloud shard per GPU; flat gradient all-reduced over RCCL in %d buckets)"
                                          % (world, len(flat.buckets)),
                           "resident_batches": NUM_BATCHES, "params": flat.num_parameters, "launch_mode": "eager",
-                          "sampling_streams": s3dis_net.SAMPLING_STREAMS,
+                          "sampling_streams": s3dis_net.SAMPLING_STREAMS, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
                           "atan2": args.atan2,
                           "world_size": dist.get_world_size() if dist.is_initialized() else 1,
                           "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
@@ -599,12 +599,17 @@ def main():
                          "configs 2, 3 and 5 with the same JSON contract (per-GPU batch 32 / 64 / 1, weak scaling)")
     ap.add_argument("--sampling-streams", type=int, default=0,
                     help="HIP streams the plans' sampling chains rotate over (0 = the line's default: 1 for the training lines "
-                         "whose step outweighs its sampling chain, 2 for --eval and scannet, where the chain is what a step waits for)")
+                         "whose step outweighs its sampling chain, 2 for --eval, 4 for scannet (with GPU_MAX_HW_QUEUES=8), where the chain is what a step waits for)")
     ap.add_argument("--eval", action="store_true",
                     help="SECONDARY line: forward only (is_training=False under no_grad: every separable layer is ONE kernel, "
                          "csrc/sepconv.hip) on the headline's batch; metric 'point-cloud blocks/sec (inference)'")
     args = ap.parse_args()
 
+    if args.config == "scannet":
+        # four sampling streams + the graph and the main stream: the runtime multiplexes a process's streams onto 4 hardware
+        # queues by default, and two sampling chains on one queue run one behind the other (tools/exp_scannet_timeline.py);
+        # read when the HIP runtime starts, so it is set before the first device call
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_self_launch(args))
     rank, world, local_rank = hdist.init_from_env()
