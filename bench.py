@@ -605,10 +605,13 @@ def main():
                          "csrc/sepconv.hip) on the headline's batch; metric 'point-cloud blocks/sec (inference)'")
     args = ap.parse_args()
 
-    if args.config == "scannet":
-        # four sampling streams + the graph and the main stream: the runtime multiplexes a process's streams onto 4 hardware
-        # queues by default, and two sampling chains on one queue run one behind the other (tools/exp_scannet_timeline.py);
-        # read when the HIP runtime starts, so it is set before the first device call
+    if args.config == "scannet" or args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # The runtime multiplexes a process's streams onto 4 hardware queues by default, and two streams on one queue run one
+        # behind the other (tools/exp_scannet_timeline.py: a third sampling stream's chain waited for another's).  scannet: four
+        # sampling streams + the graph and the main stream.  Multi-rank runs: RCCL's streams come on top of the step's three,
+        # and a gradient bucket's all-reduce queued behind a 1.7-ms sampling kernel would be waited for before Adam.  (One
+        # GPU, three streams: 1814 blocks/s with 8 queues against 1820-1840 — left at the default there.)  The variable is read
+        # when the HIP runtime starts, so it is set before the first device call (the self-launched ranks inherit it).
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_self_launch(args))
@@ -802,7 +805,7 @@ def main():
                        "parallelism": "dp%d (one cloud shard per GPU; flat gradient all-reduced over RCCL in %d buckets, "
                                       "overlapped with backward)" % (world, len(flat.buckets)),
                        "resident_batches": NUM_BATCHES, "event_pass_steps": ev_steps,
-                       "params": nparams, "launch_mode": mode,
+                       "params": nparams, "launch_mode": mode, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
                        "atan2": args.atan2,
                        "bin_ids": ("bit-identical to the reference build (same ocml atan2f; tests/test_gpu_round3.py)" if args.atan2 == "ocml"
                                    else "shared correctly-rounded atan2f: == CPU oracle, differs from the reference build within an "
