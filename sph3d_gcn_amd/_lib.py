@@ -184,6 +184,7 @@ class _Proxy:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(st)
+                e0.raw_stream = st.cuda_stream          # (for timelines: tools/exp_step_timeline.py)
                 rc = _fn(*args)
                 e1.record(st)
                 _timing.append((_name, tuple(args[i] for i in _pos if i < len(args)), e0, e1))
