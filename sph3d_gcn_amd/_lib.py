@@ -261,3 +261,69 @@ def scratch(nbytes, device, slot=0):
         t = torch.empty((nbytes + nbytes // 4,), dtype=torch.uint8, device=device)
         _scratch[key] = t
     return t
+
+
+# ---- one allocation per graph plan and producing stream ----------------------------------------------------------------------
+# The tensors of a graph plan (neighbour lists, bins, samples, transposed graphs: ~110 per S3DIS step) are produced on side streams
+# and read by the main stream's kernels, so each is `record_stream`-ed for the main stream — and the caching allocator then records
+# ONE EVENT PER BLOCK AND STREAM when a block is freed.  A step frees them in a burst (when the transposed-graph cache evicts the
+# step's entries), and ~100 event records are ~100 marker packets in the main stream's queue: 0.47 ms in which no kernel of the
+# feature path runs (tools/exp_step_timeline.py: the gap at the start of every step; gone when nothing is freed).  With all
+# outputs of a plan's stream carved from ONE block, the burst is one event per stream.  An arena is sized by the plan that came
+# before it (same shapes): the first plan of a shape allocates tensor by tensor and only measures.
+class Arena:
+    __slots__ = ("device", "cap", "off", "need", "_i32", "_f32", "buf")
+
+    def __init__(self, nbytes, device):
+        """allocates on the CURRENT stream (the stream whose kernels will write the tensors)"""
+        self.device, self.cap, self.off, self.need = device, int(nbytes), 0, 0
+        self.buf = torch.empty((self.cap,), dtype=torch.uint8, device=device) if self.cap > 0 else None
+        self._i32 = self.buf.view(torch.int32) if self.buf is not None else None
+        self._f32 = self.buf.view(torch.float32) if self.buf is not None else None
+
+    def take(self, shape, dtype):
+        n = 4
+        for d in shape:
+            n *= d
+        n = (n + 255) & ~255
+        self.need += n
+        if self.off + n > self.cap:
+            return None
+        base = self._i32 if dtype is torch.int32 else self._f32
+        strides, s = [], 1
+        for d in reversed(shape):
+            strides.append(s)
+            s *= d
+        strides.reverse()
+        t = torch.as_strided(base, shape, strides, self.off >> 2)
+        self.off += n
+        return t
+
+
+_arena = [None]
+
+
+class arena_scope:
+    """`with arena_scope(arena):` — _lib.empty() carves from `arena` inside (one issuing thread: no thread-local)"""
+
+    def __init__(self, arena):
+        self.arena = arena
+
+    def __enter__(self):
+        self.prev = _arena[0]
+        _arena[0] = self.arena
+        return self.arena
+
+    def __exit__(self, *exc):
+        _arena[0] = self.prev
+        return False
+
+
+def empty(shape, dtype, device):
+    """torch.empty for the OUTPUTS of graph-building ops (int32 / float32): from the active arena when there is one"""
+    a = _arena[0]
+    if a is not None and a.device == device and (dtype is torch.int32 or dtype is torch.float32):
+        t = a.take(shape, dtype)
+        if t is not None:
+            return t
+    return torch.empty(shape, dtype=dtype, device=device)

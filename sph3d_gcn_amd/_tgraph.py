@@ -126,10 +126,10 @@ def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1
     cur = torch.cuda.current_stream()
     B, M, K = nn_index.shape
     dev = nn_index.device
-    offsets = torch.empty((B * (n_src * F + 1),), dtype=torch.int32, device=dev)
-    ent_key = torch.empty((B * M * K,), dtype=torch.int32, device=dev)
-    ent_scale = torch.empty((B * M * K,), dtype=torch.float32, device=dev)
-    active = torch.empty((F + 1,), dtype=torch.int32, device=dev) if bin_index is not None else None
+    offsets = _lib.empty((B * (n_src * F + 1),), torch.int32, dev)
+    ent_key = _lib.empty((B * M * K,), torch.int32, dev)
+    ent_scale = _lib.empty((B * M * K,), torch.float32, dev)
+    active = _lib.empty((F + 1,), torch.int32, dev) if bin_index is not None else None
     l = _lib.lib()
     wsb = l.sph3d_graph_transpose_workspace(B, n_src, M, K, F)
     if counted_workspace is not None:
@@ -145,7 +145,7 @@ def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1
     if bin_index is not None and n_src >= BALANCE_MIN_POINTS and _ident(nn_index) not in _orders:
         # processing order of the convolution gradient that evens out the in-edges per wave (sph3d_graph_balanced_order);
         # an order registered by the caller (set_source_order) wins
-        order = torch.empty((B, n_src), dtype=torch.int32, device=dev)
+        order = _lib.empty((B, n_src), torch.int32, dev)
         _lib.check(l.sph3d_graph_balanced_order(B, n_src, F, _lib.ptr(offsets), _lib.ptr(order), _lib.stream_ptr()))
         set_source_order(nn_index, order)
     out = (offsets, ent_key, ent_scale, active)

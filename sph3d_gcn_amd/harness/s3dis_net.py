@@ -11,6 +11,7 @@ import types
 import torch
 import torch.nn.functional as F
 
+from .. import _lib
 from .. import sph3gcn_util as s3g_util
 
 
@@ -90,6 +91,8 @@ _side_stream = {}
 # the chains of consecutive steps overlap and take CUs from the feature path: 1763 vs 1787 blocks/s).  More when the chain is
 # what a step waits for: the forward-only loop (2: 3.51 -> 3.33 ms) and the 65 536-point plan (2: 53.4 -> 29.7 ms).
 SAMPLING_STREAMS = 1
+_USE_ARENA = True          # one allocation per plan and producing stream (GraphPlan)
+_ARENA_NEED = {}           # (points shape, config, ...) -> bytes the sampling / graph stream's tensors of such a plan took
 
 
 class GraphPlan:
@@ -165,7 +168,12 @@ class GraphPlan:
             points.record_stream(s_graph)
             if torch.is_tensor(global_query):
                 global_query.record_stream(s_graph)
-            with torch.cuda.stream(s_fps):
+            # one block per producing stream for the plan's ~110 index / graph tensors (_lib.Arena: the allocator records one
+            # event per block and consuming stream when a block is freed — a burst of ~100 marker packets in the main
+            # stream's queue per step, 0.47 ms without a kernel); sized by the previous plan of the same shapes
+            akey = (tuple(points.shape), id(config), bool(decoder), self.need_backward)
+            need = _ARENA_NEED.get(akey, (0, 0))
+            with torch.cuda.stream(s_fps), _lib.arena_scope(_lib.Arena(need[0], xyz.device) if _USE_ARENA else None) as a_fps:
                 # one contiguous copy of the coordinates for every op of the plan (the [:, :, 0:3] view made each
                 # neighbour search / binning / sampling call copy it again)
                 xyz = xyz.contiguous()
@@ -194,8 +202,15 @@ class GraphPlan:
             for t in self.xyz_layers + self.indices:
                 if torch.is_tensor(t):
                     t.record_stream(s_graph)
-            with torch.cuda.stream(s_graph):
+            with torch.cuda.stream(s_graph), _lib.arena_scope(_lib.Arena(need[1], xyz.device) if _USE_ARENA else None) as a_graph:
                 self._build_all(s_graph)
+            if _USE_ARENA:
+                # (+ 1/16: a plan on other data of the same shape may ask for a little more, e.g. another count of active bins)
+                want = (a_fps.need + (a_fps.need >> 4), a_graph.need + (a_graph.need >> 4))
+                if want[0] > need[0] or want[1] > need[1]:
+                    _ARENA_NEED[akey] = (max(want[0], need[0]), max(want[1], need[1]))
+                    while len(_ARENA_NEED) > 16:
+                        _ARENA_NEED.pop(next(iter(_ARENA_NEED)))
         else:
             if xyz_transform is not None:
                 self.xyz_layers[0] = xyz_transform(xyz)

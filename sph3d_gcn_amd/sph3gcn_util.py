@@ -235,7 +235,7 @@ def gather_nd(params, indices):
         for d in params.shape[2:]:
             row *= d
         S = indices.numel() // 2
-        out = torch.empty(tuple(indices.shape[:-1]) + tuple(params.shape[2:]), dtype=params.dtype, device=params.device)
+        out = _lib.empty(tuple(indices.shape[:-1]) + tuple(params.shape[2:]), params.dtype, params.device)
         if S and row:
             _lib.check(_lib.lib().sph3d_gather_nd(B, N, S, row, _lib.ptr(indices), _lib.ptr(params), _lib.ptr(out),
                                                  _lib.stream_ptr()))

@@ -43,7 +43,7 @@ def _spherical_kernel_impl(database: torch.Tensor, query: torch.Tensor, nn_index
     B, N, _ = database.shape
     M = query.shape[1]
     K = nn_index.shape[2]
-    filt_index = torch.empty((B, M, K), dtype=torch.int32, device=database.device)
+    filt_index = _lib.empty((B, M, K), torch.int32, database.device)
     l = _lib.lib()
     fn = l.sph3d_spherical_kernel_ocml if _atan2 == "ocml" else l.sph3d_spherical_kernel
     _lib.check(fn(

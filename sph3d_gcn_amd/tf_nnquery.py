@@ -38,9 +38,9 @@ def _build_sphere_neighbor_impl(database: torch.Tensor, query: torch.Tensor, rad
     database, query = _lib.f32(database), _lib.f32(query)
     B, N, _ = database.shape
     M = query.shape[1]
-    nn_index = torch.empty((B, M, nn_sample), dtype=torch.int32, device=database.device)
-    nn_count = torch.empty((B, M), dtype=torch.int32, device=database.device)
-    nn_dist = torch.empty((B, M, nn_sample), dtype=torch.float32, device=database.device)
+    nn_index = _lib.empty((B, M, nn_sample), torch.int32, database.device)
+    nn_count = _lib.empty((B, M), torch.int32, database.device)
+    nn_dist = _lib.empty((B, M, nn_sample), torch.float32, database.device)
     l = _lib.lib()
     # the `_ws` entry points: the search's cell grid lives in memory of OURS (torch's stream-aware allocator), the library
     # allocates nothing (include/sph3d.h)
@@ -148,10 +148,10 @@ def build_sphere_graph(xyz, radius, nnsample, kernel, with_transpose=True):
     K = int(nnsample)
     F = n * p * q + 1
     dev = xyz.device
-    nn_index = torch.empty((B, N, K), dtype=torch.int32, device=dev)
-    nn_count = torch.empty((B, N), dtype=torch.int32, device=dev)
-    nn_dist = torch.empty((B, N, K), dtype=torch.float32, device=dev)
-    filt = torch.empty((B, N, K), dtype=torch.int32, device=dev)
+    nn_index = _lib.empty((B, N, K), torch.int32, dev)
+    nn_count = _lib.empty((B, N), torch.int32, dev)
+    nn_dist = _lib.empty((B, N, K), torch.float32, dev)
+    filt = _lib.empty((B, N, K), torch.int32, dev)
     l = _lib.lib()
     ws, wsb = None, 0
     if with_transpose:
@@ -184,9 +184,9 @@ def build_sphere_neighbor_counted(database, query, radius, nnsample):
     M = query.shape[1]
     K = int(nnsample)
     dev = database.device
-    nn_index = torch.empty((B, M, K), dtype=torch.int32, device=dev)
-    nn_count = torch.empty((B, M), dtype=torch.int32, device=dev)
-    nn_dist = torch.empty((B, M, K), dtype=torch.float32, device=dev)
+    nn_index = _lib.empty((B, M, K), torch.int32, dev)
+    nn_count = _lib.empty((B, M), torch.int32, dev)
+    nn_dist = _lib.empty((B, M, K), torch.float32, dev)
     l = _lib.lib()
     wsb = l.sph3d_graph_transpose_workspace(B, N, M, K, 1)
     ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)

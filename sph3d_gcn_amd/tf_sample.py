@@ -17,7 +17,7 @@ def _farthest_point_sample_impl(database: torch.Tensor, npoint: int) -> torch.Te
         raise ValueError("FarthestPointSample expects (batch_size,num_points,3) inp shape")  # :40
     database = _lib.f32(database)
     b, n, _ = database.shape
-    out = torch.empty((b, npoint), dtype=torch.int32, device=database.device)
+    out = _lib.empty((b, npoint), torch.int32, database.device)
     l = _lib.lib()
     wsb = l.sph3d_farthest_point_sample_workspace(b, n, npoint)
     ws = _lib.scratch(wsb, database.device)
