@@ -300,28 +300,30 @@ class Arena:
         return t
 
 
-_arena = [None]
+import threading
+
+_arena = threading.local()       # (per thread: an arena belongs to the stream its creator was issuing on)
 
 
 class arena_scope:
-    """`with arena_scope(arena):` — _lib.empty() carves from `arena` inside (one issuing thread: no thread-local)"""
+    """`with arena_scope(arena):` — _lib.empty() carves from `arena` inside, on this thread"""
 
     def __init__(self, arena):
         self.arena = arena
 
     def __enter__(self):
-        self.prev = _arena[0]
-        _arena[0] = self.arena
+        self.prev = getattr(_arena, "cur", None)
+        _arena.cur = self.arena
         return self.arena
 
     def __exit__(self, *exc):
-        _arena[0] = self.prev
+        _arena.cur = self.prev
         return False
 
 
 def empty(shape, dtype, device):
     """torch.empty for the OUTPUTS of graph-building ops (int32 / float32): from the active arena when there is one"""
-    a = _arena[0]
+    a = getattr(_arena, "cur", None)
     if a is not None and a.device == device and (dtype is torch.int32 or dtype is torch.float32):
         t = a.take(shape, dtype)
         if t is not None:

@@ -314,3 +314,31 @@ def test_fused_separable_layer_support_is_what_the_launcher_can_run():
     assert l.sph3d_separable_conv3d_fused_supported(8192, 97, 256, 2, 64, 256) == 1       # [8,4,3]: fits with a lower tile
     assert l.sph3d_separable_conv3d_fused_supported(8192, 161, 256, 2, 64, 256) == 0      # 162 KB of filter slice alone
     assert l.sph3d_separable_conv3d_fused_supported(8192, 254, 128, 2, 64, 128) == 0
+
+
+def test_plan_arena_carves_aligned_views_and_falls_back():
+    """_lib.Arena / _lib.empty: the graph-building ops' outputs come from one block while a plan is being built (one allocator
+    event per block and consuming stream at free time instead of one per tensor: DESIGN section 0 item 8)"""
+    import torch
+    from sph3d_gcn_amd import _lib
+    dev = torch.device("cpu")
+    assert _lib.empty((3, 5), torch.int32, dev).shape == (3, 5)                      # no arena: a plain tensor
+    a = _lib.Arena(4096, dev)
+    with _lib.arena_scope(a):
+        x = _lib.empty((2, 3, 4), torch.int32, dev)
+        y = _lib.empty((7,), torch.float32, dev)
+        z = _lib.empty((0, 9), torch.int32, dev)
+        big = _lib.empty((2000,), torch.float32, dev)                                 # does not fit: falls back
+        other = _lib.empty((4,), torch.int64, dev)                                    # not an index / graph dtype: never from the arena
+        with _lib.arena_scope(None):
+            plain = _lib.empty((4,), torch.int32, dev)
+    base = a.buf.untyped_storage().data_ptr()
+    assert x.untyped_storage().data_ptr() == base and y.untyped_storage().data_ptr() == base
+    assert x.data_ptr() == base and y.data_ptr() == base + 256 and x.is_contiguous() and y.is_contiguous()
+    assert x.dtype == torch.int32 and y.dtype == torch.float32 and z.numel() == 0
+    assert big.untyped_storage().data_ptr() != base and other.untyped_storage().data_ptr() != base
+    assert plain.untyped_storage().data_ptr() != base
+    assert a.need == 256 + 256 + 0 + 8192                                             # what a plan of these shapes asks for
+    x.fill_(7); y.fill_(1.5)
+    assert int(x.sum()) == 7 * 24 and float(y.sum()) == 10.5                          # disjoint
+    assert _lib.empty((2,), torch.int32, dev).untyped_storage().data_ptr() != base    # scope left

@@ -123,3 +123,60 @@ def test_workspace_form_runs_under_stream_capture(dev):
     idx_o, cnt_o, dst_o = oracle.build_sphere_neighbor(xyz, xyz, radius, None, K)
     np.testing.assert_array_equal(cnt.cpu().numpy(), cnt_o)
     np.testing.assert_array_equal(idx.cpu().numpy(), idx_o)
+
+
+def test_graph_plan_tensors_share_one_block_per_stream_and_equal_the_plain_plan(dev):
+    """harness/s3dis_net.GraphPlan carves the outputs of the graph-building ops from one block per producing stream (_lib.Arena), sized
+    by the previous plan of the same shapes: the second plan's index / graph tensors share a storage per stream, and every
+    tensor equals the one a plan without arenas builds (integers: bit for bit)"""
+    from sph3d_gcn_amd import _tgraph
+    from sph3d_gcn_amd.harness import s3dis_net
+    cfg = s3dis_net.s3dis_config(2048)
+    xyz, _, _ = synth.s3dis_batch(77, 2, 2048)
+    pts = torch.from_numpy(xyz).to(dev)
+    torch.cuda.synchronize()
+
+    def tensors(plan):
+        out = {}
+        for l, g in sorted(plan._enc.items()):
+            for k, v in g.items():
+                if torch.is_tensor(v):
+                    out["enc%d.%s" % (l, k)] = v
+        for l, g in sorted(plan._dec.items()):
+            for k, v in g.items():
+                if torch.is_tensor(v):
+                    out["dec%d.%s" % (l, k)] = v
+        for i, t in enumerate(plan.indices):
+            if torch.is_tensor(t):
+                out["indices%d" % i] = t
+        for i, t in enumerate(plan.xyz_layers):
+            out["xyz%d" % i] = t
+        return out
+
+    old = s3dis_net._USE_ARENA
+    try:
+        s3dis_net._USE_ARENA = False
+        _tgraph.clear()
+        plain = s3dis_net.GraphPlan(pts, cfg)
+        torch.cuda.synchronize()
+        ref = {k: v.clone() for k, v in tensors(plain).items()}
+        s3dis_net._USE_ARENA = True
+        s3dis_net._ARENA_NEED.clear()
+        _tgraph.clear()
+        first = s3dis_net.GraphPlan(pts, cfg)              # measures
+        torch.cuda.synchronize()
+        assert len(s3dis_net._ARENA_NEED) == 1 and min(next(iter(s3dis_net._ARENA_NEED.values()))) > 0
+        _tgraph.clear()
+        second = s3dis_net.GraphPlan(pts, cfg)             # carves
+        torch.cuda.synchronize()
+    finally:
+        s3dis_net._USE_ARENA = old
+    got = tensors(second)
+    assert set(got) == set(ref)
+    for k in ref:
+        assert torch.equal(got[k], ref[k]), k
+    graph_store = {got[k].untyped_storage().data_ptr() for k in got if k.startswith(("enc", "dec")) and got[k].dtype == torch.int32}
+    assert len(graph_store) == 1, "the graph stream's index tensors of a plan live in one block"
+    plain_store = {v.untyped_storage().data_ptr() for k, v in tensors(plain).items() if k.startswith(("enc", "dec"))}
+    assert len(plain_store) > 8
+    _tgraph.clear()

@@ -7,6 +7,8 @@ import bench
 from sph3d_gcn_amd import _lib
 from sph3d_gcn_amd.harness import dist as hdist, optim as hoptim, s3dis_net, synth
 dev = torch.device("cuda:0"); _lib.lib()
+if os.environ.get("MAINSTREAM") == "1":          # experiment: the feature path on a created stream instead of the null stream
+    torch.cuda.set_stream(torch.cuda.Stream())
 B = 16
 batches = []
 for w in range(3):
