@@ -206,7 +206,9 @@ class GraphPlan:
                 self._build_all(s_graph)
             if _USE_ARENA:
                 # (+ 1/16: a plan on other data of the same shape may ask for a little more, e.g. another count of active bins)
-                want = (a_fps.need + (a_fps.need >> 4), a_graph.need + (a_graph.need >> 4))
+                # (whole 32-MB units: plans of nearby sizes then ask the caching allocator for the same block size)
+                unit = lambda n: ((n + (n >> 4) + (32 << 20) - 1) >> 25) << 25 if n > (8 << 20) else n + (n >> 4)
+                want = (unit(a_fps.need), unit(a_graph.need))
                 if want[0] > need[0] or want[1] > need[1]:
                     _ARENA_NEED[akey] = (max(want[0], need[0]), max(want[1], need[1]))
                     while len(_ARENA_NEED) > 16:
