@@ -41,7 +41,10 @@ enum {
 };
 
 /* Library identification. */
-int sph3d_abi_version(void);                 /* currently 1 */
+/* bumped whenever an exported symbol is removed or changes its signature (2: round 5 removed the sph3d_conv_plan* /
+ * sph3d_depthwise_conv3d_lds* entries; additions alone do not bump it) */
+#define SPH3D_ABI_VERSION 2
+int sph3d_abi_version(void);                 /* == SPH3D_ABI_VERSION of the header the library was built from */
 const char* sph3d_last_error(void);          /* thread-local text of the last non-OK status */
 const char* sph3d_build_info(void);          /* "gfx950 hipcc <ver> ..." */
 
@@ -370,6 +373,26 @@ int sph3d_separable_conv3d_fused(int B, int N, int M, int F, int C, int r, int K
                                  const int* nn_index, const int* nn_count, const int* bin_index, const float* input,
                                  const float* depthwise_filter, const float* pointwise_weights, const float* bias,
                                  const float* scale, const float* shift, float* output, sph3d_stream_t stream);
+
+/* ---- fused separable convolution for TRAINING ("BN stats as a side reduction") ----------------------------------
+ * The layer of utils/sph3gcn_util.py:134-161 with is_training=True up to the batch-norm statistics, in one barrier-free kernel
+ * (csrc/sepring.hip): DepthwiseConv3d (tf_conv3d.cpp:34-107 / tf_conv3d_gpu.cu:7-29) -> matmul with
+ * pointwise_weights[C*r][Cout] (+ bias[Cout], NULL: none).  Writes
+ *   depthwise_output [B, M, C*r]   the depthwise tensor (operand of the weight gradient; not re-read by the forward pass),
+ *   y                [B, M, Cout]  the raw product (what sph3d_elu_bn_backward needs),
+ *   partial          [nblk][2][Cout]  per (workgroup, wave group) sum elu(y), sum elu(y)^2 over its rows — the layout
+ *                    sph3d_elu_bn_forward_partials consumes; nblk = sph3d_separable_conv3d_train_blocks(Cout).
+ * Shapes: r in {1, 2}, C % 4 == 0, C <= 128, C*r <= 256, Cout in {16, 32, 64, 128, 256}, F <= 254
+ * (sph3d_separable_conv3d_train_supported() -> 1 | 0; SPH3D_EUNSUPPORTED otherwise: run sph3d_depthwise_conv3d +
+ * sph3d_pointwise_gemm_bnstats).  The same kernel without the two extra outputs serves sph3d_separable_conv3d_fused on
+ * these shapes.  sph3d_separable_conv3d_ring_failures(): 1 if a launch ever gave up waiting (never expected; synchronises). */
+int sph3d_separable_conv3d_train_supported(int N, int F, int C, int r, int K, int Cout);
+int sph3d_separable_conv3d_train_blocks(int Cout);
+int sph3d_separable_conv3d_train(int B, int N, int M, int F, int C, int r, int K, int Cout,
+                                 const int* nn_index, const int* nn_count, const int* bin_index, const float* input,
+                                 const float* depthwise_filter, const float* pointwise_weights, const float* bias,
+                                 float* depthwise_output, float* y, float* partial, sph3d_stream_t stream);
+int sph3d_separable_conv3d_ring_failures(void);
 
 /* ---- the 1x1 layer with few outputs over two operand halves (the logits layer) ------------------------------------------------
  * tf.concat((unpooled, skip), axis=2) followed by pointwise_conv3d to num_cls outputs (models/SPH3D_s3dis.py:104-108,

@@ -81,6 +81,10 @@ SIGNATURES = {
     "sph3d_pointwise_gemm_skinny_tn": (_I, [_I] * 4 + [_P] * 5 + [_S, _P]),
     "sph3d_separable_conv3d_fused_supported": (_I, [_I] * 6),
     "sph3d_separable_conv3d_fused": (_I, [_I] * 9 + [_P] * 11),
+    "sph3d_separable_conv3d_train_supported": (_I, [_I] * 6),
+    "sph3d_separable_conv3d_train_blocks": (_I, [_I]),
+    "sph3d_separable_conv3d_train": (_I, [_I] * 8 + [_P] * 11),
+    "sph3d_separable_conv3d_ring_failures": (_I, []),
     "sph3d_elu_bn_forward_partials": (_I, [_I] * 3 + [_P] * 6 + [_F, _F] + [_P] * 4),
     "sph3d_elu_bn_forward": (_I, [_I, _I, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _S, _P]),
     "sph3d_elu_bn_backward": (_I, [_I, _I] + [_P] * 5 + [_I] + [_P] * 3 + [_P, _S, _P]),
@@ -90,6 +94,7 @@ _EXTRA = {
     "sph3d_selftest_math": (_I, [_I, _P, _P, _P, _P, _P, _P, _P]),
 }
 
+ABI_VERSION = 2          # include/sph3d.h: SPH3D_ABI_VERSION
 _lib = None
 
 
@@ -117,8 +122,8 @@ def lib():
                 continue
             fn.restype = res
             fn.argtypes = args
-    if l.sph3d_abi_version() != 1:
-        raise Sph3dError("libsph3d.so ABI version mismatch")
+    if l.sph3d_abi_version() != ABI_VERSION:
+        raise Sph3dError("libsph3d.so ABI version %d, this package binds version %d" % (l.sph3d_abi_version(), ABI_VERSION))
     _lib = _Proxy(l)
     return _lib
 
@@ -142,7 +147,7 @@ def timing_stop():
 
 
 _PURE = ("_workspace", "_blocks", "_supported", "_parts")
-_NO_TIME = ("sph3d_abi_version", "sph3d_last_error", "sph3d_build_info", "workspace", "_release_", "_blocks", "_supported", "_launches", "_parts")
+_NO_TIME = ("sph3d_abi_version", "sph3d_last_error", "sph3d_build_info", "workspace", "_release_", "_blocks", "_supported", "_launches", "_parts", "_failures")
 
 
 class _Proxy:

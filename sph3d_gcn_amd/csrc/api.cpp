@@ -85,7 +85,7 @@ int release_scratch(hipStream_t stream, bool all_streams)
 }
 }  // namespace sph3d
 
-extern "C" int sph3d_abi_version(void) { return 1; }
+extern "C" int sph3d_abi_version(void) { return SPH3D_ABI_VERSION; }
 extern "C" const char* sph3d_last_error(void) { return sph3d::g_err; }
 extern "C" int sph3d_release_stream_scratch(sph3d_stream_t stream) { return sph3d::release_scratch((hipStream_t)stream, false); }
 extern "C" int sph3d_release_all_scratch(void) { return sph3d::release_scratch(nullptr, true); }

@@ -48,6 +48,32 @@ static inline hipStream_t as_stream(sph3d_stream_t s) { return reinterpret_cast<
 // large fills go through a kernel that covers the chip (8 us for the same buffer), small ones stay with the runtime.
 int zero_async(void* p, size_t bytes, hipStream_t stream, const char* what);
 
+// ---- workspace layout of the transposed-graph build (graph.hip; the fused neighbour search of nnquery.hip / nngrid.hip writes
+// the counting phase's three arrays itself) ----
+//   deg[B*L]        in-degree of every (source, bin) segment, L = N*F; the fill cursors' zero state after the scan
+//   bin_used[F]     1 for every bin that occurs
+//   status[B*chunks]  64-bit (flag << 32 | value) words of the single-pass scan (decoupled look-back), chunks = ceil(L / 2048)
+//   slot_pos[B*M*K] position of every edge inside its segment
+// deg .. status are ONE zero fill (tg_zero_words words from deg).
+constexpr int kTgChunk = 2048;
+struct TgWs {
+    int* deg; int* bin_used; unsigned long long* status; int* slot_pos; int L; int chunks; size_t zero_words; size_t total_words;
+};
+static inline TgWs tg_ws(void* workspace, int B, int N, int M, int K, int F)
+{
+    TgWs w;
+    w.L = N * F;
+    w.chunks = (w.L + kTgChunk - 1) / kTgChunk;
+    const size_t head = ((size_t)B * w.L + (size_t)F + 1) & ~(size_t)1;         // status words are 8-byte aligned
+    w.deg = (int*)workspace;
+    w.bin_used = w.deg + (size_t)B * w.L;
+    w.status = reinterpret_cast<unsigned long long*>(w.deg + head);
+    w.zero_words = head + 2 * (size_t)B * w.chunks;
+    w.slot_pos = w.deg + w.zero_words;
+    w.total_words = w.zero_words + (size_t)B * M * K;
+    return w;
+}
+
 // ---- device helpers -----------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 

@@ -597,13 +597,12 @@ static int build_sphere_graph_impl(bool ocml, int B, int N, int M, int nn_sample
             set_error("build_sphere_graph: transpose workspace %zu B < required %zu B", transpose_workspace_bytes, need);
             return SPH3D_EWORKSPACE;
         }
-        // layout of graph.hip: counters [B*N*F], bin flags [F], chunk sums, slot positions [B*M*K]
-        const size_t L = (size_t)N * F;
-        const size_t chunks = (L + 2047) / 2048;
-        fx.deg = (int*)transpose_workspace;
-        fx.binUsed = fx.deg + (size_t)B * L;
-        fx.slotPos = fx.binUsed + F + (size_t)B * chunks;
-        int rc = zero_async(fx.deg, sizeof(int) * ((size_t)B * L + F), as_stream(stream), "build_sphere_graph: memset");
+        // layout of graph.hip (common.hpp: tg_ws): counters, bin flags and scan status words (one zero fill), slot positions
+        const TgWs w = tg_ws(transpose_workspace, B, N, M, nn_sample, F);
+        fx.deg = w.deg;
+        fx.binUsed = w.bin_used;
+        fx.slotPos = w.slot_pos;
+        int rc = zero_async(w.deg, sizeof(int) * w.zero_words, as_stream(stream), "build_sphere_graph: memset");
         if (rc) return rc;
     }
     bool fused = false;

@@ -15,6 +15,7 @@
 // k-order of the product: lane (i = lane % 16, kq = lane / 16) supplies A[i][16t + 4kq + u] and B[16t + 4kq + u][j] at step
 // (t, u): any pairing is legal as long as A and B use the same one, and this one makes a lane's four A values of a t ONE
 // ds_read_b128.  fp32 MFMA is exact fp32 FMA arithmetic; results differ from the separate kernels by summation order only.
+#include <cstdlib>
 #include "common.hpp"
 
 namespace sph3d {
@@ -492,6 +493,12 @@ static int sc_launch(int B, int N, int M, int F, int C, int K, int Cout, int act
     return check_launch("sph3d_separable_conv3d_fused");
 }
 
+// sepring.hip: the same layer without barriers (claim counter + ring of row blocks); covers C <= 128, C*r <= 256, Cout a power of two
+bool sepring_infer_ok(int N, int F, int C, int r, int K, int Cout);
+int sepring_infer(int B, int N, int M, int F, int C, int r, int K, int Cout, int act, const int* nn_index, const int* nn_count,
+                  const int* bin_index, const float* input, const float* dw_filter, const float* W, const float* bias,
+                  const float* scale, const float* shift, float* output, hipStream_t st);
+
 }  // namespace sph3d
 
 using namespace sph3d;
@@ -518,6 +525,11 @@ extern "C" int sph3d_separable_conv3d_fused(int B, int N, int M, int F, int C, i
     }
     if (B == 0 || M == 0) return SPH3D_OK;
     hipStream_t st = as_stream(stream);
+    // SPH3D_SC_RING: 1 (default) the barrier-free kernel wherever it covers the shape, 0 never (A/B measurements)
+    static const bool use_ring = !(getenv("SPH3D_SC_RING") && atoi(getenv("SPH3D_SC_RING")) == 0);
+    if (use_ring && sepring_infer_ok(N, F, C, r, K, Cout))
+        return sepring_infer(B, N, M, F, C, r, K, Cout, act, nn_index, nn_count, bin_index, input, depthwise_filter,
+                             pointwise_weights, bias, scale, shift, output, st);
     if (!small) {
         // the layers whose pointwise weights do not fit a wave's registers: accumulators resident, W streamed per k slice
         if (C <= 64)

@@ -14,6 +14,7 @@ libsph3d's HIP kernels.  TF1-isms are mapped as follows:
 """
 import contextlib
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -352,6 +353,21 @@ def separable_conv3d(inputs,
             shift = beta - moving_mean * scale
         return tf_conv3d.separable_conv3d_fused(inputs, depthwise_kernel, kernel, nn_index, nn_count, filt_index, bias=biases,
                                                 elu=activation_fn is elu, scale=scale, shift=shift)
+    training = True if is_training is None else bool(is_training)
+    if (FUSE_SEPARABLE_TRAINING and training and with_bn and activation_fn is elu and FUSE_ELU_BN and inputs.is_cuda
+            and getattr(tf_conv3d, "separable_train_supported", None) is not None
+            and tf_conv3d.separable_train_supported(inputs, depthwise_kernel, nn_index, num_out_channels)
+            and (FUSE_SEPARABLE_TRAINING is True
+                 or _fused_train_pays(nn_index.shape[0] * nn_index.shape[1], num_in_channels, depth_multiplier, num_out_channels))):
+        # training: depthwise gather + pointwise product + statistics partials in one barrier-free kernel (csrc/sepring.hip);
+        # the depthwise tensor is written for the weight gradient but not re-read; same variables, same order of creation
+        store = get_variable_store()
+        kernel = _variable_with_weight_decay(scope + '/weights', shape=[num_in_channels * depth_multiplier, num_out_channels],
+                                             use_xavier=use_xavier, stddev=stddev, with_decay=weight_decay)
+        biases = store.get_variable(scope + '/biases', [num_out_channels], _constant(0.0)) if with_bias else None
+        gamma, beta, moving_mean, moving_var = _bn_variables(store, scope + '/bn', num_out_channels)
+        return tf_conv3d.separable_conv3d_elu_bn_train(inputs, depthwise_kernel, kernel, gamma, beta, moving_mean, moving_var,
+                                                       nn_index, nn_count, filt_index, bias=biases)
     outputs = tf_conv3d.depthwise_conv3d(inputs, depthwise_kernel, nn_index, nn_count, filt_index)
 
     batch_size = outputs.shape[0]
@@ -466,6 +482,22 @@ FUSE_LOGITS_CONCAT = True         # pointwise_conv3d_concat: few-output layer ov
 #                     at 6144 x 1024 -> 512 the per-tile W reads cost more than the depthwise tensor's round trip saves);
 #   True: wherever the kernel covers the shape;  False: never.
 FUSE_SEPARABLE_INFERENCE = "auto"
+
+
+# is_training=True: separable_conv3d + ELU + batch norm with the depthwise gather, the pointwise product and the statistics
+# partials in ONE kernel (tf_conv3d.separable_conv3d_elu_bn_train; csrc/sepring.hip) where the kernel covers the shape.
+#   False (default): never — measured, tools/exp_sepconv_training.py / profiles/r06_exp_sepconv_training.log: on the four layer
+#       shapes of the S3DIS plan the kernel covers the one-kernel forward takes what the gather and the product take one after the
+#       other (level 0: 300 vs 297 us at C = 128, 163 vs 146 at C = 64; level 1: 74 vs 77, 52 vs 51): with 16 register-limited
+#       waves per CU a wave's MFMA block sits on the same dependent path as its gathers, and in training the depthwise tensor is
+#       written anyway (the weight gradient's operand); headline 1911 vs 1918 blocks/s in three alternating pairs;
+#   "auto": layers of at least _FUSED_TRAIN_MIN_ROWS output points;  True: wherever the kernel covers the shape.
+FUSE_SEPARABLE_TRAINING = {"0": False, "1": True, "auto": "auto"}.get(os.environ.get("SPH3D_FUSE_TRAIN", ""), False)      # (env: A/B runs of bench.py)
+_FUSED_TRAIN_MIN_ROWS = int(os.environ.get("SPH3D_FUSE_TRAIN_MIN_ROWS", "16384"))
+
+
+def _fused_train_pays(rows, C, r, Cout):
+    return rows >= _FUSED_TRAIN_MIN_ROWS
 
 
 def _fused_rows_pay(rows, C, r, Cout):

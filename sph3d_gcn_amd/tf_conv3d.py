@@ -203,6 +203,73 @@ def separable_conv3d_fused(input, filter, weights, nn_index, nn_count, bin_index
                                             e if shift is None else shift, 1 if elu else 0, nn_index, nn_count, bin_index)
 
 
+# ---- the separable layer in TRAINING mode as one kernel + the ELU/BN apply (csrc/sepring.hip) --------------------
+def separable_train_supported(input, filter, nn_index, num_out_channels):
+    """shapes sph3d_separable_conv3d_train covers: r in {1, 2}, C % 4 == 0, C <= 128, C*r <= 256, Cout in {16 .. 256} a power of two"""
+    if not (input.is_cuda and input.dim() == 3 and filter.dim() == 3 and nn_index.dim() == 3):
+        return False
+    return bool(_lib.lib().sph3d_separable_conv3d_train_supported(input.shape[1], filter.shape[0], input.shape[2],
+                                                                  filter.shape[2], nn_index.shape[2], int(num_out_channels)))
+
+
+def _separable_conv3d_train_impl(input, filter, weights, bias, nn_index, nn_count, bin_index):
+    """-> depthwise [B, M, C*r], y [B, M, Cout] = depthwise @ weights (+ bias), partial [nblk, 2, Cout] (sum elu(y), sum elu(y)^2)"""
+    _lib.require_device(input, filter, weights, nn_index, nn_count, bin_index)
+    _check_conv(input, filter, nn_index, nn_count, bin_index)
+    input, filter, weights = _lib.f32(input), _lib.f32(filter), _lib.f32(weights)
+    nn_index, nn_count, bin_index = _lib.i32(nn_index), _lib.i32(nn_count), _lib.i32(bin_index)
+    B, N, C = input.shape
+    F, _, r = filter.shape
+    M, K = nn_index.shape[1], nn_index.shape[2]
+    Cout = weights.shape[1]
+    if weights.shape[0] != C * r:
+        raise ValueError("pointwise weights should be [C*r, Cout]")
+    l = _lib.lib()
+    nblk = l.sph3d_separable_conv3d_train_blocks(Cout)
+    dw = torch.empty((B, M, C * r), dtype=torch.float32, device=input.device)
+    y = torch.empty((B, M, Cout), dtype=torch.float32, device=input.device)
+    partial = torch.empty((nblk, 2, Cout), dtype=torch.float32, device=input.device)
+    _lib.check(l.sph3d_separable_conv3d_train(B, N, M, F, C, r, K, Cout, _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(bin_index),
+                                              _lib.ptr(input), _lib.ptr(filter), _lib.ptr(weights),
+                                              _lib.ptr(None if bias is None else _lib.f32(bias)), _lib.ptr(dw), _lib.ptr(y),
+                                              _lib.ptr(partial), _lib.stream_ptr()))
+    return dw, y, partial
+
+
+class _SeparableTrainFn(torch.autograd.Function):
+    """batch_norm(elu(depthwise_conv3d(input, filter) @ weights + bias)) with the batch's statistics: forward = the fused kernel
+    + the statistics finalize / apply; backward = exactly the separate ops' backward passes (ELU+BN gradient, the product's two
+    gradients, the depthwise gradients over the transposed graph)."""
+
+    @staticmethod
+    def forward(ctx, input, filter, weights, bias, gamma, beta, moving_mean, moving_var, nn_index, nn_count, bin_index):
+        from . import tf_norm
+        dw, y, partial = _separable_conv3d_train_impl(input, filter, weights, bias, nn_index, nn_count, bin_index)
+        Cout = y.shape[-1]
+        out, save_mean, save_rstd = tf_norm._elu_bn_partials_impl(y.view(-1, Cout), partial, gamma, beta, moving_mean, moving_var)
+        ctx.save_for_backward(input, filter, weights, dw, y, gamma, save_mean, save_rstd, nn_index, nn_count, bin_index)
+        ctx.has_bias = bias is not None
+        return out.view(y.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import tf_gemm, tf_norm
+        input, filter, weights, dw, y, gamma, save_mean, save_rstd, nn_index, nn_count, bin_index = ctx.saved_tensors
+        Cout = y.shape[-1]
+        dy, dgamma, dbeta = tf_norm._bwd_impl(y.view(-1, Cout), dout.reshape(-1, Cout), gamma, save_mean, save_rstd, True)
+        ddw = tf_gemm._pointwise_gemm_impl(dy, weights, True).view(dw.shape)
+        dweights = tf_gemm._pointwise_gemm_tn_impl(dw.view(-1, dw.shape[-1]), dy) if ctx.needs_input_grad[2] else None
+        dbias = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
+        gi, gf = _depthwise_conv3d_grad_impl(input, filter, ddw, nn_index, nn_count, bin_index)
+        return gi, gf, dweights, dbias, dgamma, dbeta, None, None, None, None, None
+
+
+def separable_conv3d_elu_bn_train(input, filter, weights, gamma, beta, moving_mean, moving_var, nn_index, nn_count, bin_index,
+                                  bias=None):
+    """training-mode separable layer with the ELU -> batch-norm tail: [B, M, Cout]; updates the moving statistics"""
+    return _SeparableTrainFn.apply(input, filter, weights, bias, gamma, beta, moving_mean, moving_var, nn_index, nn_count, bin_index)
+
+
 # ---- the depthwise convolution over a channel concatenation [a | b] that is never materialised (a decoder level's input) ------
 def concat_supported(input_a, input_b, filter):
     if not (input_a.is_cuda and input_b.is_cuda and input_a.dim() == 3 and input_a.shape[:2] == input_b.shape[:2] and filter.dim() == 3):

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
 def test_host_side_validation_without_gpu():
     from sph3d_gcn_amd import _lib
     l = _lib.lib()
-    assert l.sph3d_abi_version() == 1
+    assert l.sph3d_abi_version() == 2 == _lib.ABI_VERSION
     # n must be > 2 and even (tf_buildkernel.cpp:43): rejected before any launch
     rc = l.sph3d_spherical_kernel(1, 4, 4, 4, 3, 2, 2, 0.1, None, None, None, None, None, None, None)
     assert rc == -1 and b"n_" in l.sph3d_last_error()
