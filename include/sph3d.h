@@ -205,6 +205,12 @@ int sph3d_graph_transpose_finish(int B, int N, int M, int K, int F,
                                  const int* nn_index, const int* nn_count, const int* bin_index,
                                  const float* weight, int* offsets, int* ent_key, float* ent_scale, int* active_bins,
                                  void* workspace, size_t workspace_bytes, sph3d_stream_t stream);
+/* sph3d_graph_transpose_finish that also writes sph3d_graph_balanced_order's permutation (order[B*N]; NULL: none) from inside its
+ * fill launch: scan (one pass) + fill/order = two launches per graph. */
+int sph3d_graph_transpose_finish_ordered(int B, int N, int M, int K, int F,
+                                         const int* nn_index, const int* nn_count, const int* bin_index,
+                                         const float* weight, int* offsets, int* ent_key, float* ent_scale, int* active_bins,
+                                         int* order, void* workspace, size_t workspace_bytes, sph3d_stream_t stream);
 /* A processing order for sph3d_depthwise_conv3d_grad_t (its source_order argument) that balances the in-edges over the
  * gradient kernel's waves: inside windows of 2048 consecutive source points the points are sorted by in-degree (read from
  * `offsets` of the transposed graph with F bins), alternately descending and ascending.  order[B*N], a permutation per

@@ -49,6 +49,7 @@ SIGNATURES = {
     "sph3d_graph_transpose": (_I, [_I] * 5 + [_P] * 8 + [_P, _S, _P]),
     "sph3d_graph_transpose_count": (_I, [_I] * 5 + [_P] * 3 + [_I, _P, _S, _P]),
     "sph3d_graph_transpose_finish": (_I, [_I] * 5 + [_P] * 8 + [_P, _S, _P]),
+    "sph3d_graph_transpose_finish_ordered": (_I, [_I] * 5 + [_P] * 9 + [_P, _S, _P]),
     "sph3d_build_sphere_graph": (_I, [_I, _I, _I, _I, _F, _I, _I, _I] + [_P] * 6 + [_P, _S, _P]),
     "sph3d_build_sphere_graph_ocml": (_I, [_I, _I, _I, _I, _F, _I, _I, _I] + [_P] * 6 + [_P, _S, _P]),
     "sph3d_depthwise_conv3d_grad_t_workspace": (_S, [_I] * 5),

@@ -132,21 +132,21 @@ def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1
     active = _lib.empty((F + 1,), torch.int32, dev) if bin_index is not None else None
     l = _lib.lib()
     wsb = l.sph3d_graph_transpose_workspace(B, n_src, M, K, F)
-    if counted_workspace is not None:
-        _lib.check(l.sph3d_graph_transpose_finish(B, n_src, M, K, F, _lib.ptr(nn_index), _lib.ptr(nn_count),
-                                                  _lib.ptr(bin_index), _lib.ptr(weight), _lib.ptr(offsets), _lib.ptr(ent_key),
-                                                  _lib.ptr(ent_scale), _lib.ptr(active), _lib.ptr(counted_workspace), wsb,
-                                                  _lib.stream_ptr()))
-    else:
-        ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
-        _lib.check(l.sph3d_graph_transpose(B, n_src, M, K, F, _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(bin_index),
-                                           _lib.ptr(weight), _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale),
-                                           _lib.ptr(active), _lib.ptr(ws), wsb, _lib.stream_ptr()))
+    # processing order of the convolution gradient that evens out the in-edges per wave (sph3d_graph_balanced_order), written by
+    # the fill launch itself; an order registered by the caller (set_source_order) wins
+    order = None
     if bin_index is not None and n_src >= BALANCE_MIN_POINTS and _ident(nn_index) not in _orders:
-        # processing order of the convolution gradient that evens out the in-edges per wave (sph3d_graph_balanced_order);
-        # an order registered by the caller (set_source_order) wins
         order = _lib.empty((B, n_src), torch.int32, dev)
-        _lib.check(l.sph3d_graph_balanced_order(B, n_src, F, _lib.ptr(offsets), _lib.ptr(order), _lib.stream_ptr()))
+    if counted_workspace is None:
+        counted_workspace = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
+        _lib.check(l.sph3d_graph_transpose_count(B, n_src, M, K, F, _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(bin_index),
+                                                 1 if bin_index is not None else 0, _lib.ptr(counted_workspace), wsb,
+                                                 _lib.stream_ptr()))
+    _lib.check(l.sph3d_graph_transpose_finish_ordered(B, n_src, M, K, F, _lib.ptr(nn_index), _lib.ptr(nn_count),
+                                                      _lib.ptr(bin_index), _lib.ptr(weight), _lib.ptr(offsets), _lib.ptr(ent_key),
+                                                      _lib.ptr(ent_scale), _lib.ptr(active), _lib.ptr(order),
+                                                      _lib.ptr(counted_workspace), wsb, _lib.stream_ptr()))
+    if order is not None:
         set_source_order(nn_index, order)
     out = (offsets, ent_key, ent_scale, active)
     ev = torch.cuda.Event()

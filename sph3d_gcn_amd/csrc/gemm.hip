@@ -224,6 +224,9 @@ struct Dma {
 #ifndef SPH3D_GEMM_DMA
 #define SPH3D_GEMM_DMA 1
 #endif
+#ifndef SPH3D_GEMM_NBUF
+#define SPH3D_GEMM_NBUF 2     // tile images of the LDS-DMA pipeline; 3 (tiles below 128 x 128): measured round 6, per shape and in the step: no change (profiles/r06_exp_gemm_nbuf.log)
+#endif
 #ifndef SPH3D_GEMM_WGS
 #define SPH3D_GEMM_WGS 5      // workgroups per CU the unguarded BK = 16 kernels are built for
 #endif
@@ -251,7 +254,11 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? (SPH3D_GEMM_DMA != 0 &&
     constexpr int LDK = BK + 4;
     constexpr bool DMA = SPH3D_GEMM_DMA != 0 && !GUARD && BK == 16;       // LDS-DMA staging (see Dma)
     constexpr int WM = BMT / 2, WN = BN / 2;     // wave sub-tile
-    constexpr int LDSF = DMA ? cmax_i(2 * (BMT + BN) * BK, 4 * 32 * (WN == 64 ? WN : WN + 4)) : 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
+    // LDS-DMA staging depth: tile t+2 is in flight while tile t is multiplied wherever three tile images still leave the
+    // occupancy alone (every tile but 128 x 128); with two images a k-tile iteration cannot be shorter than one memory round
+    // trip (the loads issued at its top are waited for at its bottom): SPH3D_GEMM_NBUF
+    constexpr int NBUF = DMA ? ((SPH3D_GEMM_NBUF >= 3 && (BMT + BN) <= 192) ? 3 : 2) : 2;
+    constexpr int LDSF = DMA ? cmax_i(NBUF * (BMT + BN) * BK, 4 * 32 * (WN == 64 ? WN : WN + 4)) : 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
     __shared__ __attribute__((aligned(16))) float lds[LDSF];
     constexpr int TM = WM / 32, TN = WN / 32;    // MFMA tiles per wave
 
@@ -310,6 +317,60 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? (SPH3D_GEMM_DMA != 0 &&
         const size_t bstep = BKM ? (size_t)BK : (size_t)BK * ldb;
         da.issue(abase, lds);
         db.issue(bbase, lds + ABUF);
+        if constexpr (NBUF == 3) {
+            constexpr int NL = Dma<AK, BMT>::NI + Dma<BKM, BN>::NI;          // loads a wave has in flight per tile
+            const bool two = (k_begin + BK) < k_end;
+            if (two) {
+                abase += astep;
+                bbase += bstep;
+                da.issue(abase, lds + BUFD);
+                db.issue(bbase, lds + BUFD + ABUF);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");      // tile 0 has landed, tile 1 may still fly
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            int buf = 0;
+            for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+                const bool more = (k0 + BK) < k_end, more2 = (k0 + 2 * BK) < k_end;
+                if (more2) {                  // tile t+2 -> the image tile t-1 was read from (every wave is past that iteration's barrier)
+                    const int nb = buf >= 1 ? buf - 1 : 2;
+                    abase += astep;
+                    bbase += bstep;
+                    da.issue(abase, lds + nb * BUFD);
+                    db.issue(bbase, lds + nb * BUFD + ABUF);
+                }
+                const float* ca = lds + buf * BUFD;
+                const float* cb = ca + ABUF;
+                if (kSetPrio) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+                for (int g = 0; g < BK / 8; g++) {
+                    f32x4 af[TM], bf[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; i++) af[i] = Dma<AK, BMT>::frag(ca, wm + i * 32 + li, g, lk);
+#pragma unroll
+                    for (int j = 0; j < TN; j++) bf[j] = Dma<BKM, BN>::frag(cb, wn + j * 32 + li, g, lk);
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; s4++) {
+#pragma unroll
+                        for (int i = 0; i < TM; i++)
+#pragma unroll
+                            for (int j = 0; j < TN; j++) {
+                                const float av = s4 == 0 ? af[i].x : (s4 == 1 ? af[i].y : (s4 == 2 ? af[i].z : af[i].w));
+                                const float bv = s4 == 0 ? bf[j].x : (s4 == 1 ? bf[j].y : (s4 == 2 ? bf[j].z : bf[j].w));
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                            }
+                    }
+                }
+                if (kSetPrio) __builtin_amdgcn_s_setprio(0);
+                if (more) {                   // this wave's share of tile t+1 has landed (tile t+2 may still fly)
+                    if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();              // ONE barrier per k-tile
+                buf = buf == 2 ? 0 : buf + 1;
+            }
+        } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int buf = 0;
@@ -347,6 +408,7 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? (SPH3D_GEMM_DMA != 0 &&
             if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of tile t+1 has landed
             __syncthreads();              // ONE barrier per k-tile
             buf ^= 1;
+        }
         }
     } else {
     SA sa;

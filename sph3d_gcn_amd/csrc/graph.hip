@@ -70,12 +70,14 @@ __global__ __launch_bounds__(256) void tg_count(int B, int N, int M, int K, int 
     }
 }
 
-// Exclusive scan of the per-cloud counter arrays (L = N*F counters per cloud) in three fully parallel passes:
-//   tg_chunk_sums : one 256-thread block per chunk of kChunk counters -> its sum
-//   tg_scan_sums  : one block per cloud scans its (<= 1024) chunk sums in LDS
-//   tg_apply      : every chunk re-scans itself from its base, writes offsets and clears the counters (they
-//                   become the fill cursors)
-constexpr int kChunk = 2048;
+// Exclusive scan of the per-cloud counter arrays (L = N*F counters per cloud) in ONE pass (round 6; three kernels before:
+// chunk sums, scan of the sums, apply — and a fourth for the active-bin list): a 256-thread block per chunk of kTgChunk counters
+// scans its chunk, publishes the chunk's sum in a 64-bit status word (flag << 32 | value; flag 1 = the chunk's own sum, 2 = the
+// inclusive prefix up to and including the chunk) and obtains its base by looking back over its predecessors' words — a whole
+// wave at a time, 64 words per trip ("decoupled look-back").  Blocks are dispatched in index order and a block only ever waits for
+// blocks of lower index, so the wait is bounded by work that is already running.  Clouds are independent scans (cloud b owns
+// the entry slab starting at b*M*K).  The block behind the last chunk writes the active-bin list.
+constexpr int kChunk = kTgChunk;
 
 __device__ __forceinline__ int block_exclusive_scan_256(int v, int* lds, int& total)
 {
@@ -95,69 +97,9 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int* lds, int& to
     return incl - v;
 }
 
-__global__ __launch_bounds__(256) void tg_chunk_sums(int L, int chunks, const int* __restrict__ deg, int* __restrict__ sums)
-{
-    __shared__ int lds[256];
-    const int b = (int)blockIdx.x / chunks, c = (int)blockIdx.x % chunks;
-    const int* d = deg + (size_t)b * L;
-    const int lo = c * kChunk;
-    int s = 0;
-    for (int i = lo + (int)threadIdx.x; i < lo + kChunk && i < L; i += 256) s += d[i];
-    int total;
-    block_exclusive_scan_256(s, lds, total);
-    if (threadIdx.x == 0) sums[blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(256) void tg_scan_sums(int chunks, int MK, int* __restrict__ sums)
-{
-    __shared__ int lds[256];
-    const int b = (int)blockIdx.x;
-    int* s = sums + (size_t)b * chunks;
-    int run = b * MK;                      // cloud b owns the entry slab starting at b*M*K
-    for (int base = 0; base < chunks; base += 256) {
-        const int i = base + (int)threadIdx.x;
-        const int v = i < chunks ? s[i] : 0;
-        int total;
-        const int ex = block_exclusive_scan_256(v, lds, total);
-        if (i < chunks) s[i] = run + ex;
-        run += total;
-    }
-}
-
-__global__ __launch_bounds__(256) void tg_apply(int L, int chunks, int* __restrict__ deg, const int* __restrict__ sums,
-                                                int* __restrict__ offsets)
-{
-    __shared__ int lds[256];
-    const int b = (int)blockIdx.x / chunks, c = (int)blockIdx.x % chunks;
-    int* d = deg + (size_t)b * L;
-    int* off = offsets + (size_t)b * ((size_t)L + 1);
-    const int lo = c * kChunk;
-    constexpr int PER = kChunk / 256;
-    const int t0 = lo + (int)threadIdx.x * PER;
-    int v[PER];
-    int s = 0;
-#pragma unroll
-    for (int j = 0; j < PER; j++) {
-        v[j] = (t0 + j) < L ? d[t0 + j] : 0;
-        s += v[j];
-    }
-    int total;
-    int run = sums[blockIdx.x] + block_exclusive_scan_256(s, lds, total);
-#pragma unroll
-    for (int j = 0; j < PER; j++) {
-        if ((t0 + j) < L) {
-            off[t0 + j] = run;
-            d[t0 + j] = 0;
-        }
-        run += v[j];
-    }
-    if (c == chunks - 1 && threadIdx.x == 255) off[L] = run;     // end of the cloud's last segment
-}
-
 // active_bins = [count, ascending list of the bins that occur anywhere in the graph] (conv gradient, compact variant)
-__global__ __launch_bounds__(256) void tg_active_bins(int F, const int* __restrict__ binUsed, int* __restrict__ active)
+__device__ __forceinline__ void active_bins_block(int F, const int* __restrict__ binUsed, int* __restrict__ active, int* lds)
 {
-    __shared__ int lds[256];
     int run = 0;
     for (int base = 0; base < F; base += 256) {
         const int f = base + (int)threadIdx.x;
@@ -170,18 +112,89 @@ __global__ __launch_bounds__(256) void tg_active_bins(int F, const int* __restri
     if (threadIdx.x == 0) active[0] = run;
 }
 
+__global__ __launch_bounds__(256) void tg_scan(int B, int L, int chunks, int MK, int F, int* __restrict__ deg,
+                                               unsigned long long* __restrict__ status, int* __restrict__ offsets,
+                                               const int* __restrict__ binUsed, int* __restrict__ active)
+{
+    __shared__ int lds[256];
+    __shared__ int s_base;
+    if ((int)blockIdx.x == B * chunks) {             // the extra block: list of the bins that occur
+        active_bins_block(F, binUsed, active, lds);
+        return;
+    }
+    const int b = (int)blockIdx.x / chunks, c = (int)blockIdx.x % chunks;
+    int* d = deg + (size_t)b * L;
+    int* off = offsets + (size_t)b * ((size_t)L + 1);
+    unsigned long long* st = status + (size_t)b * chunks;
+    const int lo = c * kChunk;
+    constexpr int PER = kChunk / 256;
+    const int t0 = lo + (int)threadIdx.x * PER;
+    int v[PER];
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        v[j] = (t0 + j) < L ? d[t0 + j] : 0;
+        s += v[j];
+    }
+    int total;
+    const int ex = block_exclusive_scan_256(s, lds, total);
+    if (threadIdx.x < 64) {
+        // wave 0: publish, look back, publish again
+        const int lane = (int)threadIdx.x;
+        int base = b * MK;
+        if (c > 0) {
+            if (lane == 0)
+                __hip_atomic_store(&st[c], (1ull << 32) | (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int hi = c - 1;                          // nearest predecessor not yet accounted for
+            for (;;) {
+                const int i = hi - lane;
+                unsigned long long w = 2ull << 32;   // in front of the cloud's first chunk: inclusive prefix 0
+                if (i >= 0) {
+                    do {
+                        w = __hip_atomic_load(&st[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } while ((w >> 32) == 0);
+                }
+                const unsigned long long incl = __ballot((w >> 32) == 2);
+                const int first = incl ? (int)__builtin_ctzll(incl) : 64;       // nearest predecessor with an inclusive prefix
+                int part = lane <= first ? (int)(unsigned)w : 0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+                base += part;
+                if (incl) break;
+                hi -= 64;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&st[c], (2ull << 32) | (unsigned)(base - b * MK + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_base = base;
+        }
+    }
+    __syncthreads();
+    int run = s_base + ex;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        if ((t0 + j) < L) {
+            off[t0 + j] = run;
+            d[t0 + j] = 0;
+        }
+        run += v[j];
+    }
+    if (c == chunks - 1 && threadIdx.x == 255) off[L] = run;     // end of the cloud's last segment
+}
+
 // one wave per graph row (b, m), lane = neighbour slot: no per-element 64-bit divisions, the row's count and 1/count
-// are wave-uniform, the id / bin / slot reads are coalesced 256-byte rows
-__global__ __launch_bounds__(256) void tg_fill(int B, int N, int M, int K, int F, const int* __restrict__ nnIndex,
-                                               const int* __restrict__ nnCount, const int* __restrict__ binIndex,
-                                               const float* __restrict__ weight, const int* __restrict__ offsets,
-                                               const int* __restrict__ slotPos, int* __restrict__ entKey,
-                                               float* __restrict__ entScale)
+// are wave-uniform, the id / bin / slot reads are coalesced 256-byte rows.  (fb = first fill block, nfb = fill blocks of the launch)
+__device__ __forceinline__ void tg_fill_rows(int fb, int nfb, int B, int N, int M, int K, int F, const int* __restrict__ nnIndex,
+                                             const int* __restrict__ nnCount, const int* __restrict__ binIndex,
+                                             const float* __restrict__ weight, const int* __restrict__ offsets,
+                                             const int* __restrict__ slotPos, int* __restrict__ entKey,
+                                             float* __restrict__ entScale)
 {
     const int lane = (int)threadIdx.x & 63;
+    const int wpb = (int)blockDim.x >> 6;                   // waves per block
     const long long nrows = (long long)B * M;
-    const long long wstride = (long long)gridDim.x * 4;
-    for (long long row = (long long)blockIdx.x * 4 + ((int)threadIdx.x >> 6); row < nrows; row += wstride) {
+    const long long wstride = (long long)nfb * wpb;
+    for (long long row = (long long)((int)blockIdx.x - fb) * wpb + ((int)threadIdx.x >> 6); row < nrows; row += wstride) {
         const int cnt = nnCount[row];
         if (cnt <= 0) continue;
         const int b = (int)(row / M);                       // once per row
@@ -318,27 +331,78 @@ extern "C" int sph3d_spatial_order(int B, int N, const float* xyz, int* order, s
 }
 
 
-// bytes of scratch the build itself needs (the in-degree / cursor array)
-extern "C" size_t sph3d_graph_transpose_workspace(int B, int N, int M, int K, int F)
+// Degree-balanced processing order for the convolution gradient.  Its persistent workgroups deal a cloud's source points to
+// their waves position by position (wave g takes positions g, g + stride, ...), and the in-degree of the sources is
+// heavy-tailed (S3DIS level 0: mean 48, sigma 45, max 537: the first-K rule favours low indices), so in index order the
+// busiest wave of an XCD gets 1.4x the mean number of edges.  Inside every window of 2048 consecutive sources this kernel
+// sorts the sources by in-degree — descending in even windows, ascending in odd ones — so that the positions a wave visits
+// run through all the degree quantiles: level-0 gradient 0.53 -> 0.46 ms (C = 128), 0.36 -> 0.31 ms (C = 64).
+// One workgroup per (window, cloud): bitonic sort of unique keys (degree, local index) in LDS — deterministic.
+constexpr int kOrderWindow = 2048;
+__device__ __forceinline__ void balanced_order_window(int win, int b, int N, int F, const int* __restrict__ offsets,
+                                                      int* __restrict__ order, unsigned* keys)
 {
-    const size_t L = (size_t)N * F;
-    return sizeof(int) * ((size_t)B * L + (size_t)F + (size_t)B * ((L + kChunk - 1) / kChunk) + (size_t)B * M * K);
+    const int nt = (int)blockDim.x;
+    const int base = win * kOrderWindow;
+    const int cnt = (N - base) < kOrderWindow ? (N - base) : kOrderWindow;
+    const int* __restrict__ ob = offsets + (size_t)b * ((size_t)N * F + 1);
+    for (int i = (int)threadIdx.x; i < kOrderWindow; i += nt) {
+        unsigned k = 0xffffffffu;                                  // padding sorts to the end
+        if (i < cnt) {
+            const size_t n = (size_t)(base + i);
+            int deg = ob[(n + 1) * F] - ob[n * F];
+            deg = deg < (1 << 20) ? deg : (1 << 20);
+            k = ((unsigned)deg << 11) | (unsigned)i;
+        }
+        keys[i] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= kOrderWindow; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = (int)threadIdx.x; i < kOrderWindow; i += nt) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned a = keys[i], c = keys[p];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) { keys[i] = c; keys[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = (int)threadIdx.x; i < cnt; i += nt) {
+        const int src = (win & 1) ? i : (cnt - 1 - i);              // even windows: heaviest first
+        order[(size_t)b * N + base + i] = base + (int)(keys[src] & 2047u);
+    }
 }
 
-// layout of the workspace
-struct TgWs {
-    int* deg; int* bin_used; int* sums; int* slot_pos; int L; int chunks;
-};
-static TgWs tg_ws(void* workspace, int B, int N, int M, int K, int F)
+__global__ __launch_bounds__(1024) void tg_balanced_order(int N, int F, const int* __restrict__ offsets, int* __restrict__ order)
 {
-    TgWs w;
-    w.L = N * F;
-    w.chunks = (w.L + kChunk - 1) / kChunk;
-    w.deg = (int*)workspace;
-    w.bin_used = w.deg + (size_t)B * w.L;                               // [F] flags, zeroed with the counters
-    w.sums = w.bin_used + F;
-    w.slot_pos = w.sums + (size_t)B * w.chunks;                         // [B*M*K] position of every edge inside its segment
-    return w;
+    __shared__ unsigned keys[kOrderWindow];
+    balanced_order_window((int)blockIdx.x, (int)blockIdx.y, N, F, offsets, order, keys);
+}
+
+// fill pass and (order != NULL) the gradient's processing order in ONE launch: the first `nob` blocks sort one window each (the
+// longer job: they start first), the rest fill the entry arrays; both only read the scan's offsets
+__global__ __launch_bounds__(1024) void tg_fill_order(int nob, int B, int N, int M, int K, int F, const int* __restrict__ nnIndex,
+                                                      const int* __restrict__ nnCount, const int* __restrict__ binIndex,
+                                                      const float* __restrict__ weight, const int* __restrict__ offsets,
+                                                      const int* __restrict__ slotPos, int* __restrict__ entKey,
+                                                      float* __restrict__ entScale, int* __restrict__ order)
+{
+    __shared__ unsigned keys[kOrderWindow];
+    if ((int)blockIdx.x < nob) {
+        const int windows = (N + kOrderWindow - 1) / kOrderWindow;
+        balanced_order_window((int)blockIdx.x % windows, (int)blockIdx.x / windows, N, F, offsets, order, keys);
+        return;
+    }
+    tg_fill_rows(nob, (int)gridDim.x - nob, B, N, M, K, F, nnIndex, nnCount, binIndex, weight, offsets, slotPos, entKey, entScale);
+}
+
+// bytes of scratch the build itself needs (common.hpp: tg_ws)
+extern "C" size_t sph3d_graph_transpose_workspace(int B, int N, int M, int K, int F)
+{
+    return sizeof(int) * tg_ws(nullptr, B, N, M, K, F).total_words;
 }
 
 static int tg_dims_ok(int B, int N, int M, int K, int F, const void* bin_index, const void* workspace, size_t workspace_bytes)
@@ -365,7 +429,7 @@ extern "C" int sph3d_graph_transpose_count(int B, int N, int M, int K, int F, co
     if (rc || B == 0) return rc;
     hipStream_t st = as_stream(stream);
     const TgWs w = tg_ws(workspace, B, N, M, K, F);
-    rc = zero_async(w.deg, sizeof(int) * ((size_t)B * w.L + F), st, "graph_transpose: memset");
+    rc = zero_async(w.deg, sizeof(int) * w.zero_words, st, "graph_transpose: memset");       // counters, bin flags, scan status words
     if (rc) return rc;
     const long long total = (long long)B * M * K;
     long long blocks = (total + 255) / 256;
@@ -376,75 +440,45 @@ extern "C" int sph3d_graph_transpose_count(int B, int N, int M, int K, int F, co
     return check_launch("sph3d_graph_transpose_count");
 }
 
-// phase 2: scan of the counts -> offsets, then the fill pass (no atomics: every edge knows its position)
-extern "C" int sph3d_graph_transpose_finish(int B, int N, int M, int K, int F,
-                                            const int* nn_index, const int* nn_count, const int* bin_index,
-                                            const float* weight, int* offsets, int* ent_key, float* ent_scale, int* active_bins,
-                                            void* workspace, size_t workspace_bytes, sph3d_stream_t stream)
+// phase 2: scan of the counts -> offsets (+ the active-bin list), then the fill pass (no atomics: every edge knows its
+// position) together with, when `order` is given, the gradient's degree-balanced processing order: two launches
+static int tg_finish(int B, int N, int M, int K, int F, const int* nn_index, const int* nn_count, const int* bin_index,
+                     const float* weight, int* offsets, int* ent_key, float* ent_scale, int* active_bins, int* order,
+                     void* workspace, size_t workspace_bytes, sph3d_stream_t stream)
 {
     int rc = tg_dims_ok(B, N, M, K, F, bin_index, workspace, workspace_bytes);
     if (rc || B == 0) return rc;
     hipStream_t st = as_stream(stream);
     const TgWs w = tg_ws(workspace, B, N, M, K, F);
     const long long total = (long long)B * M * K;
-    long long blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    if (active_bins) hipLaunchKernelGGL(tg_active_bins, dim3(1), dim3(256), 0, st, F, w.bin_used, active_bins);
-    hipLaunchKernelGGL(tg_chunk_sums, dim3(B * w.chunks), dim3(256), 0, st, w.L, w.chunks, w.deg, w.sums);
-    hipLaunchKernelGGL(tg_scan_sums, dim3(B), dim3(256), 0, st, w.chunks, M * K, w.sums);
-    hipLaunchKernelGGL(tg_apply, dim3(B * w.chunks), dim3(256), 0, st, w.L, w.chunks, w.deg, w.sums, offsets);
-    if (total > 0) {
-        long long fb = ((long long)B * M + 3) / 4;          // one wave per graph row
-        if (fb > 65536) fb = 65536;
-        hipLaunchKernelGGL(tg_fill, dim3((unsigned)fb), dim3(256), 0, st, B, N, M, K, F, nn_index, nn_count, bin_index,
-                           weight, offsets, w.slot_pos, ent_key, ent_scale);
-    }
+    hipLaunchKernelGGL(tg_scan, dim3(B * w.chunks + (active_bins ? 1 : 0)), dim3(256), 0, st, B, w.L, w.chunks, M * K, F, w.deg,
+                       w.status, offsets, w.bin_used, active_bins);
+    const int nob = order ? B * ((N + kOrderWindow - 1) / kOrderWindow) : 0;
+    long long fb = total > 0 ? ((long long)B * M + 15) / 16 : 0;            // one wave per graph row, 16 per block
+    if (fb > 16384) fb = 16384;
+    if (nob + fb > 0)
+        hipLaunchKernelGGL(tg_fill_order, dim3((unsigned)(nob + fb)), dim3(1024), 0, st, nob, B, N, M, K, F, nn_index, nn_count,
+                           bin_index, weight, offsets, w.slot_pos, ent_key, ent_scale, order);
     return check_launch("sph3d_graph_transpose");
 }
 
-// Degree-balanced processing order for the convolution gradient.  Its persistent workgroups deal a cloud's source points to
-// their waves position by position (wave g takes positions g, g + stride, ...), and the in-degree of the sources is
-// heavy-tailed (S3DIS level 0: mean 48, sigma 45, max 537: the first-K rule favours low indices), so in index order the
-// busiest wave of an XCD gets 1.4x the mean number of edges.  Inside every window of 2048 consecutive sources this kernel
-// sorts the sources by in-degree — descending in even windows, ascending in odd ones — so that the positions a wave visits
-// run through all the degree quantiles: level-0 gradient 0.53 -> 0.46 ms (C = 128), 0.36 -> 0.31 ms (C = 64).
-// One workgroup per (window, cloud): bitonic sort of unique keys (degree, local index) in LDS — deterministic.
-constexpr int kOrderWindow = 2048;
-__global__ __launch_bounds__(1024) void tg_balanced_order(int N, int F, const int* __restrict__ offsets, int* __restrict__ order)
+extern "C" int sph3d_graph_transpose_finish(int B, int N, int M, int K, int F,
+                                            const int* nn_index, const int* nn_count, const int* bin_index,
+                                            const float* weight, int* offsets, int* ent_key, float* ent_scale, int* active_bins,
+                                            void* workspace, size_t workspace_bytes, sph3d_stream_t stream)
 {
-    __shared__ unsigned keys[kOrderWindow];
-    const int win = (int)blockIdx.x, b = (int)blockIdx.y;
-    const int base = win * kOrderWindow;
-    const int cnt = (N - base) < kOrderWindow ? (N - base) : kOrderWindow;
-    const int* __restrict__ ob = offsets + (size_t)b * ((size_t)N * F + 1);
-    for (int i = (int)threadIdx.x; i < kOrderWindow; i += 1024) {
-        unsigned k = 0xffffffffu;                                  // padding sorts to the end
-        if (i < cnt) {
-            const size_t n = (size_t)(base + i);
-            int deg = ob[(n + 1) * F] - ob[n * F];
-            deg = deg < (1 << 20) ? deg : (1 << 20);
-            k = ((unsigned)deg << 11) | (unsigned)i;
-        }
-        keys[i] = k;
-    }
-    __syncthreads();
-    for (int k = 2; k <= kOrderWindow; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = (int)threadIdx.x; i < kOrderWindow; i += 1024) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const unsigned a = keys[i], c = keys[p];
-                    const bool up = (i & k) == 0;
-                    if ((a > c) == up) { keys[i] = c; keys[p] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (int i = (int)threadIdx.x; i < cnt; i += 1024) {
-        const int src = (win & 1) ? i : (cnt - 1 - i);              // even windows: heaviest first
-        order[(size_t)b * N + base + i] = base + (int)(keys[src] & 2047u);
-    }
+    return tg_finish(B, N, M, K, F, nn_index, nn_count, bin_index, weight, offsets, ent_key, ent_scale, active_bins, nullptr, workspace,
+                     workspace_bytes, stream);
+}
+
+extern "C" int sph3d_graph_transpose_finish_ordered(int B, int N, int M, int K, int F,
+                                                    const int* nn_index, const int* nn_count, const int* bin_index,
+                                                    const float* weight, int* offsets, int* ent_key, float* ent_scale,
+                                                    int* active_bins, int* order, void* workspace, size_t workspace_bytes,
+                                                    sph3d_stream_t stream)
+{
+    return tg_finish(B, N, M, K, F, nn_index, nn_count, bin_index, weight, offsets, ent_key, ent_scale, active_bins, order, workspace,
+                     workspace_bytes, stream);
 }
 
 extern "C" int sph3d_graph_balanced_order(int B, int N, int F, const int* offsets, int* order, sph3d_stream_t stream)

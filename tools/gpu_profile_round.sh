@@ -2,7 +2,7 @@
 # One gpurun call that produces the artefacts of a round under gpurun_out/<tag>_*: default bench line, rocprofv3 kernel
 # stats + per-launch-shape durations of the same command, and separate PMC passes (traffic, then L2 hit) of the conv kernels.
 # usage: bash tools/gpu_profile_round.sh r02
-TAG=${1:-rXX}
+TAG=${1:?usage: bash tools/gpu_profile_round.sh <tag, e.g. r06>}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp

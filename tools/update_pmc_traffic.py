@@ -1,9 +1,12 @@
 """profiles/pmc_traffic.json from the per-pass counter CSVs of tools/gpu_profile_round.sh (copied into profiles/ first).
-usage: python tools/update_pmc_traffic.py [tag]   (tag = r03)
+usage: python tools/update_pmc_traffic.py <tag>   (tag = r06: REQUIRED, the round whose profiles/<tag>_* files are read; every
+value the CSVs of that round provide is rewritten and the notes are re-stamped with the tag, so the file never cites another round)
 traffic bytes per launch = FETCH_SIZE[KB] * 2 * 1024 + WRITE_SIZE[KB] * 1024 (the x2 is the gfx950 FETCH_SIZE correction of
 MI355X_MICROARCH.md for 16-B-per-lane reads, which all of these kernels issue)."""
 import csv, json, os, sys
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+if len(sys.argv) < 2:
+    sys.exit("usage: python tools/update_pmc_traffic.py <tag>   (e.g. r06)")
+TAG = sys.argv[1]
 P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles") + "/"
 
 
@@ -84,6 +87,33 @@ for key, tag in (("sph3d_pointwise_gemm_tn[131072, 256, 128]", "tn0"), ("sph3d_p
     a, b = dur_us("%s_pmc_mfma_%s.csv" % (TAG, tag), "gemm_f32_mfma"), dur_us("%s_pmc_mfma_%s.csv" % (TAG, tag), "gemm_reduce_splits")
     if a is not None:
         tu[key] = round(a + (b or 0.0), 1)          # product kernel (+ slab sum) in the isolated rocprofv3 pass of that call
+t["_round"] = TAG
+missing = [k for k in ("sph3d_depthwise_conv3d[16, 8192, 8192, 33, 128, 2, 64]", "sph3d_pointwise_gemm_tn[131072, 256, 128]") if traffic(*{
+    "sph3d_depthwise_conv3d[16, 8192, 8192, 33, 128, 2, 64]": ("fwd", "dwconv_fwd_multi"),
+    "sph3d_pointwise_gemm_tn[131072, 256, 128]": ("gemmtn0", "gemm_f32_mfma", "gemm_reduce_splits")}[k]) is None]
+if missing:
+    sys.exit("profiles/%s_pmc_* counter CSVs are missing for %s: copy the round's CSVs into profiles/ first" % (TAG, missing))
+
+
+# notes that quote another round's counters move under _history[<that round>]; the fresh note names this round's files only
+prev = t.get("_round_of_notes", "r04")
+if prev != TAG:
+    hist = t.setdefault("_history", {}).setdefault(prev, {})
+    for k in [k for k in t if k.startswith("_note") and k != "_note_gather_roofline"]:
+        hist[k] = t.pop(k)
+    for sub in ("mfma_pipe_busy", "trace_us"):
+        for k in [k for k in t.get(sub, {}) if k.startswith("_") and k != "_note"]:
+            hist[sub + "." + k] = t[sub].pop(k)
+t["_round_of_notes"] = TAG
+t["_note"] = ("Round %d (tools/gpu_profile_round.sh %s; raw per-kernel CSVs: profiles/%s_pmc_{fwd,bwd}_{FET,WRI,TCC}.csv, "
+              "profiles/%s_pmc_sq{1,2}_{fwd,bwd}.csv, profiles/%s_pmc_mfma_{nn,nt,tn,tn0}.csv, profiles/%s_pmc_gemm{nn,tn,tn0}_{FET,WRI}.csv, "
+              "profiles/%s_pmc_nnquery_{after,chain}.csv).  Separate --pmc passes per counter group.  traffic bytes per launch = "
+              "FETCH_SIZE[KB]*2*1024 + WRITE_SIZE[KB]*1024 (the x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md for "
+              "16-B-per-lane reads, which is what all of these kernels issue)." % ((int(TAG[1:]),) + (TAG,) * 6))
+t["trace_us"]["_note"] = ("rocprofv3 --kernel-trace of `python bench.py --steps 10` (profiles/%s_kernel_trace_by_launch_shape.csv): mean "
+                          "duration of the launch shape; the 128-channel gradient shares its launch shape with the smaller levels: its entry "
+                          "is the shape's MAX duration; the GEMM entries are the product kernel (+ the slab sum) in the isolated rocprofv3 "
+                          "counter pass of that call (profiles/%s_pmc_mfma_*.csv)" % (TAG, TAG))
 json.dump(t, open(P + "pmc_traffic.json", "w"), indent=1)
 print({k: v for k, v in t.items() if not k.startswith("_") and not isinstance(v, dict)})
 print(mb)
