@@ -71,3 +71,36 @@ for mode in ("full", "idle", "fps_only", "graph_only", "full", "idle"):
     host = (time.perf_counter() - t0) * 1e3 / STEPS
     torch.cuda.synchronize()
     print("%-10s device %.3f ms/step   (host issue %.2f ms/step)" % (mode, e0.elapsed_time(e1) / STEPS, host))
+
+# ---- which calls of the feature path pay: per-call device time (HIP events around every C-ABI call) by mode ----------------
+import collections
+res = {}
+for mode in ("idle", "fps_only", "graph_only", "full"):
+    for _ in range(6):
+        step(mode)
+    torch.cuda.synchronize()
+    _lib.timing_start()
+    main_raw = torch.cuda.current_stream().cuda_stream
+    for _ in range(10):
+        step(mode)
+    recs = _lib.timing_stop()
+    torch.cuda.synchronize()
+    acc = collections.defaultdict(float)
+    for name, args, e0, e1 in recs:
+        if getattr(e0, "raw_stream", None) != main_raw:
+            continue
+        acc[(name, args[:7])] += e0.elapsed_time(e1) * 1e3 / 10
+    res[mode] = acc
+keys = sorted(res["idle"], key=lambda k: -(res["full"].get(k, 0) - res["idle"][k]))
+print("\nmain-stream calls, us per step (idle | fps_only | graph_only | full), sorted by full - idle; top 25 and totals")
+for k in keys[:25]:
+    print("  %-44s %-34s %8.1f %8.1f %8.1f %8.1f" % (k[0], str(k[1]), res["idle"][k], res["fps_only"].get(k, 0), res["graph_only"].get(k, 0), res["full"].get(k, 0)))
+fam = collections.defaultdict(lambda: [0.0] * 4)
+for i, mode in enumerate(("idle", "fps_only", "graph_only", "full")):
+    for k, v in res[mode].items():
+        n = k[0]
+        f = ("gemm" if "gemm" in n else "conv grad" if "conv3d_grad" in n else "conv fwd" if "depthwise_conv3d" in n or "separable" in n
+             else "elu_bn" if "elu_bn" in n else "pool/unpool" if any(s in n for s in ("pool", "interpolate", "scatter", "gather")) else "other")
+        fam[f][i] += v
+for f, v in sorted(fam.items(), key=lambda kv: -kv[1][3]):
+    print("  family %-12s %8.1f %8.1f %8.1f %8.1f" % ((f,) + tuple(v)))
