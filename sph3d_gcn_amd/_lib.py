@@ -253,8 +253,16 @@ def ptr(t):
 
 # ---- per-stream scratch for workspaces that are dead when the call returns (gradient slabs, split-K slabs, statistics
 # partials): one grow-only buffer per (stream, slot) instead of a torch.empty per call (the step makes ~80 such allocations;
-# work on one stream is ordered, so consecutive calls may share the bytes).  NOT for memory a later call reads.
+# work on one stream is ordered, so consecutive calls may share the bytes).  NOT for memory a later call reads: every call
+# site passes it as the `workspace` of ONE C-ABI call, dead when that call's kernels are done.  release_scratch() frees.
 _scratch = {}
+
+
+def release_scratch(stream=None):
+    """drop the call-local workspaces of one raw stream handle (None: of every stream) — for a stream that is being destroyed (its
+    handle value may be recycled for a new stream of another pool) or to give the memory back; the next call allocates again"""
+    for key in [k for k in _scratch if stream is None or k[1] == stream]:
+        del _scratch[key]
 
 
 def scratch(nbytes, device, slot=0):
@@ -293,8 +301,8 @@ class Arena:
             n *= d
         n = (n + 255) & ~255
         self.need += n
-        if self.off + n > self.cap:
-            return None
+        if n == 0 or self.buf is None or self.off + n > self.cap:
+            return None          # (zero-element shapes and the measuring arena of a first plan: the caller allocates)
         base = self._i32 if dtype is torch.int32 else self._f32
         strides, s = [], 1
         for d in reversed(shape):

@@ -25,6 +25,11 @@ _generation = [0]      # bumped by clear(): entries attached to graph tensors (t
 
 
 def clear():
+    """drop every cached transpose / order (and the per-stream call workspaces of _lib).  Plan tensors carved from one _lib.Arena
+    share ONE autograd version counter (they are views of one buffer): an in-place edit of any tensor of a plan invalidates every
+    cached transpose of that plan — correct, but the backward pass then rebuilds them on the main stream.  Graph tensors are
+    outputs of the graph-building ops and are never edited in place by this package."""
+    _lib.release_scratch()
     _cache.clear()
     _orders.clear()
     _unique.clear()

@@ -342,3 +342,16 @@ def test_plan_arena_carves_aligned_views_and_falls_back():
     x.fill_(7); y.fill_(1.5)
     assert int(x.sum()) == 7 * 24 and float(y.sum()) == 10.5                          # disjoint
     assert _lib.empty((2,), torch.int32, dev).untyped_storage().data_ptr() != base    # scope left
+    # the measuring arena of a first plan (capacity 0) and zero-element shapes: plain tensors, the need still counted
+    m = _lib.Arena(0, dev)
+    with _lib.arena_scope(m):
+        e = _lib.empty((0, 9), torch.int32, dev)
+        f = _lib.empty((5,), torch.float32, dev)
+    assert e.shape == (0, 9) and f.shape == (5,) and m.need == 256 and m.buf is None
+    # call-local workspaces can be given back (per raw stream handle, or all)
+    _lib._scratch[(0, 123, 0)] = torch.empty(8)
+    _lib._scratch[(0, 456, 0)] = torch.empty(8)
+    _lib.release_scratch(123)
+    assert (0, 123, 0) not in _lib._scratch and (0, 456, 0) in _lib._scratch
+    _lib.release_scratch()
+    assert not _lib._scratch
