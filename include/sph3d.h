@@ -329,6 +329,11 @@ int sph3d_spatial_order(int B, int N, const float* xyz, int* order, sph3d_stream
 int sph3d_pointwise_gemm(int R, int Cin, int Cout,
                          const float* X, const float* W, const float* bias, int act,
                          int trans_w, float* Y, sph3d_stream_t stream);
+/* How the whole-tile products (all three, and the statistics variant) run — process-wide, returns the previous mode:
+ *   1 (default): bf16 matrix pipe with every fp32 operand cut EXACTLY into three bf16 pieces and the six leading piece products
+ *      accumulated in fp32 (csrc/gemm.hip: gemm_split_mfma) — fp32-sized error (<= 2^-23 per product), 2.7x the fp32 MFMA rate;
+ *   0: v_mfma_f32_32x32x2_f32, a k-ordered fp32 fmaf chain (what ragged shapes always take);  other values: query only. */
+int sph3d_pointwise_gemm_mode(int mode);
 int sph3d_pointwise_gemm_tn(int R, int Cin, int Cout,
                             const float* X, const float* dY, float* dW,
                             void* workspace, size_t workspace_bytes,

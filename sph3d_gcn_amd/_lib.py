@@ -67,6 +67,7 @@ SIGNATURES = {
     "sph3d_farthest_point_sample_workspace": (_S, [_I] * 3),
     "sph3d_farthest_point_sample": (_I, [_I] * 3 + [_P, _P, _P, _S, _P]),
     "sph3d_pointwise_gemm": (_I, [_I] * 3 + [_P, _P, _P, _I, _I, _P, _P]),
+    "sph3d_pointwise_gemm_mode": (_I, [_I]),
     "sph3d_pointwise_gemm_tn_workspace": (_S, [_I] * 3),
     "sph3d_pointwise_gemm_tn": (_I, [_I] * 3 + [_P, _P, _P, _P, _S, _P]),
     "sph3d_elu_bn_workspace": (_S, [_I] * 2),
@@ -148,7 +149,7 @@ def timing_stop():
 
 
 _PURE = ("_workspace", "_blocks", "_supported", "_parts")
-_NO_TIME = ("sph3d_abi_version", "sph3d_last_error", "sph3d_build_info", "workspace", "_release_", "_blocks", "_supported", "_launches", "_parts", "_failures")
+_NO_TIME = ("sph3d_abi_version", "sph3d_last_error", "sph3d_build_info", "workspace", "_release_", "_blocks", "_supported", "_launches", "_parts", "_failures", "_mode")
 
 
 class _Proxy:

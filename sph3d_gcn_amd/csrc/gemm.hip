@@ -227,10 +227,102 @@ struct Dma {
 #ifndef SPH3D_GEMM_NBUF
 #define SPH3D_GEMM_NBUF 2     // tile images of the LDS-DMA pipeline; 3 (tiles below 128 x 128): measured round 6, per shape and in the step: no change (profiles/r06_exp_gemm_nbuf.log)
 #endif
+#ifndef SPH3D_GEMM_SPLIT
+#define SPH3D_GEMM_SPLIT 1    // whole-tile products on the bf16 matrix pipe with three-way split operands (gemm_split_mfma); 0: fp32 MFMA
+#endif
 #ifndef SPH3D_GEMM_WGS
 #define SPH3D_GEMM_WGS 5      // workgroups per CU the unguarded BK = 16 kernels are built for
 #endif
 constexpr int cmax_i(int a, int b) { return a > b ? a : b; }
+
+// epilogue shared by the fp32-MFMA kernel and the split-bf16 kernel (same C/D register layout: it is dtype-independent)
+template <int BMT, int BN, int TM, int TN, bool SPLITK, bool GUARD, bool STATS, bool EPX, int LDSF>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds, int M, int N, float* __restrict__ Cmat, int ldc,
+                                              const float* __restrict__ bias, int act, float* __restrict__ stats, int tm, int ksplit,
+                                              int m0, int n0, int wave, int lane, int wm, int wn, int li, int lk)
+{
+    constexpr int WN = BN / 2;
+    // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+    float* Cout = SPLITK ? Cmat + (size_t)ksplit * ((size_t)M * ldc) : Cmat;
+    if (!GUARD) {
+        // whole tiles: stage each wave's 32 x WN slab through its own LDS region (the operand buffers are free after the
+        // loop's last barrier) and write it back as float4 rows: WN/4 lanes cover one row, 16 B per lane, instead of
+        // sixteen 4-byte stores per MFMA tile (the scalar epilogue was store-issue-bound: ~25 % of the kernel)
+        // row stride of the staging slab (floats): padded by 4, or — LDS-DMA kernels, whose operand buffers are exactly 32 KB at
+        // 128 x 128: FIVE workgroups per CU — unpadded with the column XOR-ed by 32 * (bit 2 of the row) = the lane half lk, so
+        // that the two lane halves of a store (rows 4 apart) and the four rows of a float4 read still use distinct banks
+        constexpr int EP = EPX ? WN : WN + 4;
+        static_assert(4 * 32 * EP <= LDSF, "epilogue staging must fit the operand LDS");
+        float* stage = lds + wave * (32 * EP);
+        constexpr int LPR = WN / 4;                          // lanes per row
+        constexpr int RPI = 64 / LPR;                        // rows per store instruction
+        if constexpr (STATS) {
+            // a lane's 16 x TM values of column block j all sit in ONE column (col = lane & 31): sum, fold the two lane halves,
+            // one store per (row half of the tile, column); fixed order, no atomics
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const float bv = bias != nullptr ? bias[n0 + wn + j * 32 + li] : 0.f;
+                float sz = 0.f, sq = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const float y = acc[i][j][e] + bv;
+                        const float z = y > 0.f ? y : __expf(y) - 1.f;         // == norm.hip: elu1
+                        sz += z;
+                        sq = fmaf(z, z, sq);
+                    }
+                sz += __shfl_xor(sz, 32);
+                sq += __shfl_xor(sq, 32);
+                if (lk == 0) {
+                    float* sp = stats + (size_t)(tm * 2 + (wave >> 1)) * 2 * N + n0 + wn + j * 32 + li;
+                    sp[0] = sz;
+                    sp[N] = sq;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const int col = wn + j * 32 + li;
+                const float bv = (!SPLITK && bias != nullptr) ? bias[n0 + col] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    float v = acc[i][j][e] + bv;
+                    if (!SPLITK && act == 1) v = v > 0.f ? v : expm1f(v);
+                    stage[((e & 3) + 8 * (e >> 2) + 4 * lk) * EP + ((j * 32 + li) ^ (EPX ? (lk << 5) : 0))] = v;
+                }
+            }
+            // same wave wrote and reads: LDS ops of one wave complete in order, no barrier needed
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; it++) {
+                const int r = it * RPI + lane / LPR;
+                const int c4 = (lane % LPR) * 4;
+                const float4 v = *reinterpret_cast<const float4*>(&stage[r * EP + (c4 ^ (EPX ? (((r >> 2) & 1) << 5) : 0))]);
+                *reinterpret_cast<float4*>(&Cout[(size_t)(m0 + wm + i * 32 + r) * ldc + n0 + wn + c4]) = v;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int col = n0 + wn + j * 32 + li;
+            const float bv = (!SPLITK && bias != nullptr && col < N) ? bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                if (row < M && col < N) {
+                    float v = acc[i][j][e] + bv;
+                    if (!SPLITK && act == 1) v = v > 0.f ? v : expm1f(v);     // ELU (alpha = 1)
+                    Cout[(size_t)row * ldc + col] = v;
+                }
+            }
+        }
+    }
+}
 
 // k assignment inside a group of 8 consecutive k: MFMA step s (0..3) multiplies k = 8g + s (lanes 0..31) with
 // k = 8g + 4 + s (lanes 32..63).  Any pairing is legal (the sum over k is what matters, A and B use the same one);
@@ -478,87 +570,235 @@ __global__ __launch_bounds__(256, (BK == 16 && !GUARD) ? (SPH3D_GEMM_DMA != 0 &&
 
     }
 
-    // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
-    float* Cout = SPLITK ? Cmat + (size_t)ksplit * ((size_t)M * ldc) : Cmat;
-    if (!GUARD) {
-        // whole tiles: stage each wave's 32 x WN slab through its own LDS region (the operand buffers are free after the
-        // loop's last barrier) and write it back as float4 rows: WN/4 lanes cover one row, 16 B per lane, instead of
-        // sixteen 4-byte stores per MFMA tile (the scalar epilogue was store-issue-bound: ~25 % of the kernel)
-        // row stride of the staging slab (floats): padded by 4, or — LDS-DMA kernels, whose operand buffers are exactly 32 KB at
-        // 128 x 128: FIVE workgroups per CU — unpadded with the column XOR-ed by 32 * (bit 2 of the row) = the lane half lk, so
-        // that the two lane halves of a store (rows 4 apart) and the four rows of a float4 read still use distinct banks
-        constexpr bool EPX = DMA && WN == 64;
-        constexpr int EP = EPX ? WN : WN + 4;
-        static_assert(4 * 32 * EP <= LDSF, "epilogue staging must fit the operand LDS");
-        float* stage = lds + wave * (32 * EP);
-        constexpr int LPR = WN / 4;                          // lanes per row
-        constexpr int RPI = 64 / LPR;                        // rows per store instruction
-        if constexpr (STATS) {
-            // a lane's 16 x TM values of column block j all sit in ONE column (col = lane & 31): sum, fold the two lane halves,
-            // one store per (row half of the tile, column); fixed order, no atomics
+    gemm_epilogue<BMT, BN, TM, TN, SPLITK, GUARD, STATS, DMA && WN == 64, LDSF>(acc, lds, M, N, Cmat, ldc, bias, act, stats, tm, ksplit,
+                                                                                  m0, n0, wave, lane, wm, wn, li, lk);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Split-bf16 products (round 6): the same three products on the BF16 matrix pipe — 16x the fp32 MFMA rate — at fp32 accuracy.
+// Every fp32 operand x is cut into three bf16 pieces by TRUNCATION, x = h + m + l EXACTLY (8 + 8 + 8 significant bits: h = the
+// top 16 bits of x, m = the top 16 bits of x - h, l = x - h - m, each subtraction exact), and
+//     x * y  ~=  h h' + (h m' + m h') + (m m' + h l' + l h')
+// six v_mfma_f32_32x32x16_bf16 per 32 x 32 x 16 block (192 matrix-pipe cycles against 512 for eight v_mfma_f32_32x32x2_f32),
+// products of bf16 pairs exact in the fp32 accumulator.  Dropped: m l' + l m' + l l' <= 2^-23 |x y| per product — the size of ONE
+// fp32 rounding, where the fp32 kernel's k-ordered fmaf chain commits one rounding per term; measured against float64 the two
+// kernels' errors are the same size (tests/test_gpu_gemm_split.py).  Non-finite operands: Inf - Inf makes the lower pieces NaN, so
+// an output the fp32 kernel makes +-Inf may be NaN (never finite).
+// Pipeline: global -> registers (Stage's loads: tile t+1 in flight during the MFMAs of tile t) -> split in registers -> LDS piece
+// planes [piece][k-group of 8][row][8 bf16]: a lane's MFMA operand (row = lane % 32, k-group = lane / 32) is ONE ds_read_b128, the
+// 32 lanes of a half wave read 512 contiguous bytes.  One barrier per k-tile, two plane images.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+
+struct Split3 { unsigned h, m, l; };          // each: the bf16 piece of a in the low half, of b in the high half
+__device__ __forceinline__ Split3 split_pair(float a, float b)
+{
+    Split3 r;
+    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    r.h = __builtin_amdgcn_perm(ub, ua, 0x07060302u);                       // (ua >> 16) | (ub & 0xffff0000)
+    const float ra = a - __uint_as_float(ua & 0xffff0000u), rb = b - __uint_as_float(ub & 0xffff0000u);
+    const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
+    r.m = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+    const float sa = ra - __uint_as_float(va & 0xffff0000u), sb = rb - __uint_as_float(vb & 0xffff0000u);
+    r.l = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+    return r;
+}
+
+// Operand tile of the split kernel: global -> registers -> three bf16 piece planes in LDS.
+// KMAJ (memory [row][k]): a unit = one float4 (4 consecutive k of a row) -> one 8-byte store per piece.
+// !KMAJ (memory [k][row]): a unit = 2 (k) x 4 (rows): two float4 loads along the rows (the lanes of a k cover contiguous bytes) ->
+// per row the k pair is ONE packed dword per piece (no transposing shuffles: split_pair packs its two arguments).  Always pairs —
+// with 4 x 4 blocks half of the threads have no unit at 64-row tiles and the busy half carries twice the conversion work.
+template <bool KMAJ, int BT, int BK>
+struct SplitStage {
+    static constexpr int KG = BK / 8;                       // k-groups of 8
+    static constexpr int PLANE = KG * BT * 16;              // bytes of one piece's plane
+    static constexpr int BYTES = 3 * PLANE;
+    static constexpr int KUN = KMAJ ? BK / 4 : BK / 2;      // units along k
+    static constexpr int UNITS = KMAJ ? BT * (BK / 4) : (BT / 4) * (BK / 2);
+    static constexpr int NCH = (UNITS + 255) / 256;
+    static constexpr int NREG = KMAJ ? NCH : 2 * NCH;
+    f32x4 r[NREG];
+    __device__ __forceinline__ unsigned lane_offset(int ld) const
+    {
+        const int u = (int)threadIdx.x;
+        if (KMAJ) return (unsigned)((u / KUN) * ld + (u % KUN) * 4);
+        return (unsigned)((u % KUN) * 2 * ld + (u / KUN) * 4);
+    }
+    // `base`: workgroup-uniform address of the tile's first element (see Stage::load_fast)
+    __device__ __forceinline__ void load(const float* __restrict__ base, int ld, unsigned voff)
+    {
+        if (UNITS < 256 && (int)threadIdx.x >= UNITS) return;
 #pragma unroll
-            for (int j = 0; j < TN; j++) {
-                const float bv = bias != nullptr ? bias[n0 + wn + j * 32 + li] : 0.f;
-                float sz = 0.f, sq = 0.f;
+        for (int i = 0; i < NCH; i++) {
+            if (KMAJ) {
+                const float* b = base + (size_t)(i * (256 / KUN)) * ld;                     // uniform
+                r[i] = *reinterpret_cast<const f32x4*>(b + voff);
+            } else {
+                const float* b = base + i * (256 / KUN) * 4;                                 // uniform
+                r[2 * i] = *reinterpret_cast<const f32x4*>(b + voff);
+                r[2 * i + 1] = *reinterpret_cast<const f32x4*>(b + ld + voff);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(char* img) const
+    {
+        if (UNITS < 256 && (int)threadIdx.x >= UNITS) return;
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int u = (int)threadIdx.x + i * 256;
+            if (KMAJ) {
+                const int row = u / KUN, kq = u % KUN;                  // k = 4 kq .. 4 kq + 3 of `row`
+                const f32x4 v = r[i];
+                const Split3 p0 = split_pair(v.x, v.y), p1 = split_pair(v.z, v.w);
+                char* q = img + (((kq >> 1) * BT + row) << 4) + ((kq & 1) << 3);
+                *reinterpret_cast<u32x2v*>(q) = u32x2v{p0.h, p1.h};
+                *reinterpret_cast<u32x2v*>(q + PLANE) = u32x2v{p0.m, p1.m};
+                *reinterpret_cast<u32x2v*>(q + 2 * PLANE) = u32x2v{p0.l, p1.l};
+            } else {
+                const int kq = u % KUN, rq = u / KUN;                   // k = 2 kq, 2 kq + 1 of rows 4 rq .. 4 rq + 3
+                const int k0 = kq * 2;
+                char* q = img + (((k0 >> 3) * BT + rq * 4) << 4) + ((k0 & 7) << 1);
+                const f32x4 a = r[2 * i], b = r[2 * i + 1];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const Split3 sp = split_pair(a[j], b[j]);
+                    *reinterpret_cast<unsigned*>(q + j * 16) = sp.h;
+                    *reinterpret_cast<unsigned*>(q + j * 16 + PLANE) = sp.m;
+                    *reinterpret_cast<unsigned*>(q + j * 16 + 2 * PLANE) = sp.l;
+                }
+            }
+        }
+    }
+    // piece `pc` of the lane's operand: tile row `row`, k-group g
+    __device__ __forceinline__ static bf16x8 frag(const char* img, int pc, int row, int g)
+    {
+        return *reinterpret_cast<const bf16x8*>(img + pc * PLANE + ((g * BT + row) << 4));
+    }
+};
+
+#ifndef SPH3D_SPLIT_DB
+#define SPH3D_SPLIT_DB 0      // 1: two plane images (one barrier per k-tile, 3 workgroups per CU at 128 x 128); 0: one image, two barriers, 4-5 per CU
+#endif
+template <bool AK, bool BKM, int BMT, int BN, int BK, bool SPLITK, bool STATS>
+__global__ __launch_bounds__(256, SPH3D_SPLIT_DB ? 2 : 4) void gemm_split_mfma(int M, int N, int Kd, const float* __restrict__ A, int lda,
+                                                          const float* __restrict__ B, int ldb, float* __restrict__ Cmat, int ldc,
+                                                          const float* __restrict__ bias, int act, int kchunk,
+                                                          float* __restrict__ stats = nullptr, int nsplit = 1)
+{
+    using PA = SplitStage<AK, BMT, BK>;
+    using PB = SplitStage<BKM, BN, BK>;
+    constexpr int WM = BMT / 2, WN = BN / 2;     // wave sub-tile
+    constexpr int TM = WM / 32, TN = WN / 32;    // MFMA tiles per wave
+    constexpr int BUFB = PA::BYTES + PB::BYTES;  // bytes of one plane image (A pieces, then B pieces)
+    constexpr bool DB = SPH3D_SPLIT_DB != 0;
+    constexpr bool EPX = WN == 64;               // un-padded, XOR-swizzled epilogue slab (32 KB at 128 x 128)
+    constexpr int LDSF = cmax_i((DB ? 2 : 1) * BUFB / 4, 4 * 32 * (EPX ? WN : WN + 4));
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];
+    char* img = reinterpret_cast<char*>(lds);
+
+    // XCD-aware workgroup -> tile map: as gemm_f32_mfma
+    const int tiles_n = (N + BN - 1) / BN;
+    const int tiles_m = (M + BMT - 1) / BMT;
+    const int wg = (int)blockIdx.x;
+    int tm, tn, ksplit = 0;
+    if (SPLITK) {
+        const int T = tiles_m * tiles_n;
+        const int g = wg / (8 * T), r = wg - g * 8 * T;
+        ksplit = g * 8 + (r & 7);
+        if (ksplit >= nsplit) return;
+        const int tile = r >> 3;
+        tm = tile / tiles_n;
+        tn = tile - tm * tiles_n;
+    } else {
+        const int g = wg / (8 * tiles_n), r = wg - g * 8 * tiles_n;
+        tm = g * 8 + (r & 7);
+        tn = r >> 3;
+        if (tm >= tiles_m) return;
+    }
+    const int m0 = tm * BMT, n0 = tn * BN;
+    const int k_begin = SPLITK ? ksplit * kchunk : 0;
+    const int k_end = SPLITK ? ((k_begin + kchunk) < Kd ? (k_begin + kchunk) : Kd) : Kd;
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+    const int li = lane & 31, lk = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    PA sa;
+    PB sb;
+    const float* abase = AK ? A + (size_t)m0 * lda + k_begin : A + (size_t)k_begin * lda + m0;
+    const float* bbase = BKM ? B + (size_t)n0 * ldb + k_begin : B + (size_t)k_begin * ldb + n0;
+    const size_t astep = AK ? (size_t)BK : (size_t)BK * lda;
+    const size_t bstep = BKM ? (size_t)BK : (size_t)BK * ldb;
+    const unsigned aoff = sa.lane_offset(lda), boff = sb.lane_offset(ldb);
+    sa.load(abase, lda, aoff);
+    sb.load(bbase, ldb, boff);
+    sa.store(img);
+    sb.store(img + PA::BYTES);
+    __syncthreads();
+
+    int buf = 0;
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        const bool more = (k0 + BK) < k_end;
+        if (more) {                       // global -> registers for tile t+1 while tile t is multiplied
+            abase += astep;
+            bbase += bstep;
+            sa.load(abase, lda, aoff);
+            sb.load(bbase, ldb, boff);
+        }
+        const char* ca = img + (DB ? buf * BUFB : 0);
+        const char* cb = ca + PA::BYTES;
+        if (kSetPrio) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+        for (int s16 = 0; s16 < BK / 16; s16++) {
+            const int g = 2 * s16 + lk;
+            bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int pc = 0; pc < 3; pc++) af[i][pc] = PA::frag(ca, pc, wm + i * 32 + li, g);
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int pc = 0; pc < 3; pc++) bf[j][pc] = PB::frag(cb, pc, wn + j * 32 + li, g);
+            // small terms first; consecutive MFMAs write different accumulators where there is more than one
+#pragma unroll
+            for (int t = 0; t < 6; t++) {
+                const int pa = t == 0 ? 0 : (t == 1 ? 2 : (t == 2 ? 1 : (t == 3 ? 0 : (t == 4 ? 1 : 0))));      // A piece: h l m h m h
+                const int pb = t == 0 ? 2 : (t == 1 ? 0 : (t == 2 ? 1 : (t == 3 ? 1 : (t == 4 ? 0 : 0))));      // B piece: l h m m h h
 #pragma unroll
                 for (int i = 0; i < TM; i++)
 #pragma unroll
-                    for (int e = 0; e < 16; e++) {
-                        const float y = acc[i][j][e] + bv;
-                        const float z = y > 0.f ? y : __expf(y) - 1.f;         // == norm.hip: elu1
-                        sz += z;
-                        sq = fmaf(z, z, sq);
-                    }
-                sz += __shfl_xor(sz, 32);
-                sq += __shfl_xor(sq, 32);
-                if (lk == 0) {
-                    float* sp = stats + (size_t)(tm * 2 + (wave >> 1)) * 2 * N + n0 + wn + j * 32 + li;
-                    sp[0] = sz;
-                    sp[N] = sq;
-                }
+                    for (int j = 0; j < TN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][pa], bf[j][pb], acc[i][j], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-#pragma unroll
-            for (int j = 0; j < TN; j++) {
-                const int col = wn + j * 32 + li;
-                const float bv = (!SPLITK && bias != nullptr) ? bias[n0 + col] : 0.f;
-#pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    float v = acc[i][j][e] + bv;
-                    if (!SPLITK && act == 1) v = v > 0.f ? v : expm1f(v);
-                    stage[((e & 3) + 8 * (e >> 2) + 4 * lk) * EP + ((j * 32 + li) ^ (EPX ? (lk << 5) : 0))] = v;
-                }
+        if (kSetPrio) __builtin_amdgcn_s_setprio(0);
+        if (DB) {
+            if (more) {                   // the other image: nobody reads it during this iteration
+                sa.store(img + (buf ^ 1) * BUFB);
+                sb.store(img + (buf ^ 1) * BUFB + PA::BYTES);
             }
-            // same wave wrote and reads: LDS ops of one wave complete in order, no barrier needed
-#pragma unroll
-            for (int it = 0; it < 32 / RPI; it++) {
-                const int r = it * RPI + lane / LPR;
-                const int c4 = (lane % LPR) * 4;
-                const float4 v = *reinterpret_cast<const float4*>(&stage[r * EP + (c4 ^ (EPX ? (((r >> 2) & 1) << 5) : 0))]);
-                *reinterpret_cast<float4*>(&Cout[(size_t)(m0 + wm + i * 32 + r) * ldc + n0 + wn + c4]) = v;
+            __syncthreads();              // ONE barrier per k-tile
+            buf ^= 1;
+        } else {
+            __syncthreads();              // every wave has its fragments of tile t in registers / the matrix pipe
+            if (more) {
+                sa.store(img);
+                sb.store(img + PA::BYTES);
             }
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; i++) {
-#pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int col = n0 + wn + j * 32 + li;
-            const float bv = (!SPLITK && bias != nullptr && col < N) ? bias[col] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-                if (row < M && col < N) {
-                    float v = acc[i][j][e] + bv;
-                    if (!SPLITK && act == 1) v = v > 0.f ? v : expm1f(v);     // ELU (alpha = 1)
-                    Cout[(size_t)row * ldc + col] = v;
-                }
-            }
+            __syncthreads();
         }
     }
+    gemm_epilogue<BMT, BN, TM, TN, SPLITK, false, STATS, EPX, LDSF>(acc, lds, M, N, Cmat, ldc, bias, act, stats, tm, ksplit, m0, n0, wave,
+                                                                      lane, wm, wn, li, lk);
 }
 
 __global__ __launch_bounds__(256) void gemm_reduce_splits(int nsplit, int total, const float* __restrict__ partial,
@@ -601,6 +841,15 @@ static unsigned gemm_grid(long long tiles_m, long long tiles_n, long long nsplit
 
 static bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 
+// whole-tile products on the bf16 pipe with split operands (gemm_split_mfma) unless SPH3D_GEMM_SPLIT=0 (A/B runs; the exact
+// fp32-MFMA kernels then); ragged shapes always take the fp32 kernels
+static int g_split_mode = -1;          // -1: not decided yet (environment / build default)
+static bool split_on()
+{
+    if (g_split_mode < 0) g_split_mode = getenv("SPH3D_GEMM_SPLIT") ? (atoi(getenv("SPH3D_GEMM_SPLIT")) != 0) : (SPH3D_GEMM_SPLIT != 0);
+    return g_split_mode != 0;
+}
+
 template <bool AK, bool BKM, bool GUARD>
 static void launch_gemm_tiles(int M, int N, int Kd, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                               const float* bias, int act, hipStream_t st)
@@ -611,6 +860,25 @@ static void launch_gemm_tiles(int M, int N, int Kd, const float* A, int lda, con
     static const long long kMinTiles = getenv("SPH3D_GEMM_MINTILES") ? atoi(getenv("SPH3D_GEMM_MINTILES")) : 512;      // (experiments)
     // (BK = 32 at two workgroups per CU for the big grids: measured slower than BK = 16 at four, before and after the
     //  round-2 register fix: 0.101 vs 0.094 ms at (131072, 256 -> 128))
+    if constexpr (!GUARD) {
+        if (split_on()) {
+            // 64 x 64 tiles take two MFMA k-steps per barrier where K allows.  SPH3D_SPLIT_MINTILES: experiments
+            static const long long kMinTiles = getenv("SPH3D_SPLIT_MINTILES") ? atoi(getenv("SPH3D_SPLIT_MINTILES")) : 512;
+            if (N > 64 && ntiles(128, 128) >= kMinTiles)
+                hipLaunchKernelGGL((gemm_split_mfma<AK, BKM, 128, 128, 16, false, false>), dim3(gemm_grid((M + 127) / 128, (N + 127) / 128)), dim3(256),
+                                   0, st, M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
+            else if (!BKM && N <= 64 && ntiles(128, 64) >= kMinTiles)
+                hipLaunchKernelGGL((gemm_split_mfma<AK, BKM, 128, 64, 16, false, false>), dim3(gemm_grid((M + 127) / 128, (N + 63) / 64)), dim3(256), 0,
+                                   st, M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
+            else if (Kd % 32 == 0)
+                hipLaunchKernelGGL((gemm_split_mfma<AK, BKM, 64, 64, 32, false, false>), dim3(gemm_grid((M + 63) / 64, (N + 63) / 64)), dim3(256), 0,
+                                   st, M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
+            else
+                hipLaunchKernelGGL((gemm_split_mfma<AK, BKM, 64, 64, 16, false, false>), dim3(gemm_grid((M + 63) / 64, (N + 63) / 64)), dim3(256), 0,
+                                   st, M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
+            return;
+        }
+    }
     if (BKM && !(N > 64 && ntiles(128, 128) >= kMinTiles)) {
         // input-gradient product (W stored [n][k]) below 2 big tiles per CU: 64x64 tiles (0.071 vs 0.088 ms at
         // (6144, 2048 -> 256) ... ) -- with >= kMinTiles big tiles the 128x128 kernel wins since its prefetch registers stopped
@@ -685,6 +953,13 @@ static void tn_plan(int R, int Cin, int Cout, int& bn, int& tiles, int& nsplit, 
 
 using namespace sph3d;
 
+extern "C" int sph3d_pointwise_gemm_mode(int mode)
+{
+    const int prev = split_on() ? 1 : 0;
+    if (mode == 0 || mode == 1) g_split_mode = mode;
+    return prev;
+}
+
 extern "C" int sph3d_pointwise_gemm(int R, int Cin, int Cout, const float* X, const float* W, const float* bias, int act,
                                     int trans_w, float* Y, sph3d_stream_t stream)
 {
@@ -715,6 +990,21 @@ extern "C" int sph3d_pointwise_gemm_bnstats(int R, int Cin, int Cout, const floa
     }
     hipStream_t st = as_stream(stream);
     const unsigned tiles = gemm_grid(R / bm, Cout / bn);
+    if (split_on()) {
+        if (bm == 128 && bn == 128)
+            hipLaunchKernelGGL((gemm_split_mfma<true, false, 128, 128, 16, false, true>), dim3(tiles), dim3(256), 0, st, R, Cout, Cin, X, Cin, W,
+                               Cout, Y, Cout, bias, 0, 0, partial);
+        else if (bm == 128)
+            hipLaunchKernelGGL((gemm_split_mfma<true, false, 128, 64, 16, false, true>), dim3(tiles), dim3(256), 0, st, R, Cout, Cin, X, Cin, W,
+                               Cout, Y, Cout, bias, 0, 0, partial);
+        else if (Cin % 32 == 0)
+            hipLaunchKernelGGL((gemm_split_mfma<true, false, 64, 64, 32, false, true>), dim3(tiles), dim3(256), 0, st, R, Cout, Cin, X, Cin, W,
+                               Cout, Y, Cout, bias, 0, 0, partial);
+        else
+            hipLaunchKernelGGL((gemm_split_mfma<true, false, 64, 64, 16, false, true>), dim3(tiles), dim3(256), 0, st, R, Cout, Cin, X, Cin, W,
+                               Cout, Y, Cout, bias, 0, 0, partial);
+        return check_launch("sph3d_pointwise_gemm_bnstats");
+    }
     if (bm == 128 && bn == 128)
         hipLaunchKernelGGL((gemm_f32_mfma<true, false, 128, 128, BKS, false, false, true>), dim3(tiles), dim3(256), 0, st, R, Cout, Cin, X,
                            Cin, W, Cout, Y, Cout, bias, 0, 0, partial);
@@ -757,6 +1047,14 @@ extern "C" int sph3d_pointwise_gemm_tn(int R, int Cin, int Cout, const float* X,
                        Cin, dY, Cout, out, Cout, nullptr, 0, kchunk, nullptr, nsplit)
     // whole tiles: BK = 16 at four workgroups per CU (8 + 8 prefetch registers with the 2x4 transposing units): 0.786 vs
     // 0.855 ms over the step's shapes against BK = 32 at two per CU
+    if (whole && split_on()) {
+        if (bn == 128)
+            hipLaunchKernelGGL((gemm_split_mfma<false, false, 128, 128, 16, true, false>), dim3(gemm_grid(tiles, 1, nsplit)), dim3(256), 0, st, Cin,
+                               Cout, R, X, Cin, dY, Cout, out, Cout, nullptr, 0, kchunk, nullptr, nsplit);
+        else
+            hipLaunchKernelGGL((gemm_split_mfma<false, false, 128, 64, 16, true, false>), dim3(gemm_grid(tiles, 1, nsplit)), dim3(256), 0, st, Cin,
+                               Cout, R, X, Cin, dY, Cout, out, Cout, nullptr, 0, kchunk, nullptr, nsplit);
+    } else
     if (whole) { if (bn == 128) SPH3D_TN16(128); else SPH3D_TN16(64); }
     else if (bn == 128) SPH3D_TN(128, true);
     else SPH3D_TN(64, true);

@@ -12,6 +12,7 @@ def timeit(fn,n=10):
     return e0.elapsed_time(e1)/n
 shapes=[(131072,3,64),(131072,128,128),(131072,256,128),(32768,256,256),(32768,512,256),(12288,512,256),(6144,512,512),(6144,1024,512),(2048,1024,512),(6144,2048,256),(12288,1024,256),(32768,1024,128),(131072,256,13)]
 tot_h=tot_b=0
+import os
 for R,Ci,Co in shapes:
     x=torch.randn(R,Ci,device=dev); w=torch.randn(Ci,Co,device=dev); dy=torch.randn(R,Co,device=dev)
     fl=2*R*Ci*Co/1e9
