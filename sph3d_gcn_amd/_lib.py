@@ -163,7 +163,7 @@ class _Proxy:
         # (reached once per symbol: the result is stored on the instance, so later look-ups never come here — 180 look-ups per
         # step at 2 us each otherwise)
         fn = getattr(self._cdll, name)     # AttributeError if not exported
-        if any(k in name for k in _PURE):
+        if any(k in name for k in _PURE) and name != "sph3d_pointwise_gemm_bnstats_blocks":
             # pure functions of their integer arguments (workspace sizes, shape predicates): a step asks ~75 of them, always
             # for the same shapes — answered from a dict instead of a foreign call each time
             memo = {}
