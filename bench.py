@@ -44,6 +44,8 @@ PRIME_STEPS = 16
 NUM_POINT = 8192
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # dense (MI355X_MICROARCH.md); the split products execute 6 bf16 piece products per fp32 product
+SPLIT_PRODUCTS = 6
 
 
 def algorithmic_bytes(name, a):
@@ -552,7 +554,8 @@ def secondary_main(args, rank, world, dev, pinned_cpus):
         if best is not None and best[0] > 0:
             work, cname, ints, avg_s = best
             gemm = "gemm" in cname
-            peak = FP32_MFMA_PEAK_TFLOPS if gemm else HBM_PEAK_GBS
+            peak = ((round(BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS, 1) if _lib.lib().sph3d_pointwise_gemm_mode(-1) else FP32_MFMA_PEAK_TFLOPS)
+                    if gemm else HBM_PEAK_GBS)
             ach = work / (1e12 if gemm else 1e9) / avg_s
             roofline = {"kernel": cname, "family": fname, "dims": list(ints[:7]), "bound": "mfma" if gemm else "hbm",
                         "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s" if gemm else "GB/s", "frac": round(ach / peak, 4),
@@ -744,9 +747,19 @@ def main():
         avg_s = ms / cnt / 1e3
         is_gemm = "gemm" in name
         iso_s = isolated_call_seconds(name, ints, dev)
+        gemm_split = bool(_lib.lib().sph3d_pointwise_gemm_mode(-1))
         if is_gemm:
             R_, Ci_, Co_ = ints[:3]
-            work, peak, unit, bound = 2.0 * R_ * Ci_ * Co_ / 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", "mfma"
+            # split mode (the default): the whole-tile products run on the BF16 matrix pipe, six piece products per fp32 product
+            # (include/sph3d.h: sph3d_pointwise_gemm_mode): the fp32-equivalent ceiling is the dense bf16 peak / 6
+            mfma_peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS if gemm_split else FP32_MFMA_PEAK_TFLOPS
+            flops = 2.0 * R_ * Ci_ * Co_
+            # the roof that binds this call: its FLOPs at the matrix peak or its algorithmic bytes at the HBM peak, whichever takes longer
+            # (on the bf16 pipe the level-0 products — K = 128 / 256 — are bound by their bytes)
+            if flops / 1e12 / mfma_peak >= ab / 1e9 / HBM_PEAK_GBS:
+                work, peak, unit, bound = flops / 1e12, round(mfma_peak, 1), "TFLOP/s", "mfma"
+            else:
+                work, peak, unit, bound = ab / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
         else:
             work, peak, unit, bound = ab / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
         achieved = work / avg_s
@@ -770,6 +783,15 @@ def main():
                     "family_ms_per_step": round(fam[fname][0] / ev_steps, 3),
                     "note": "avg_us: HIP events around the C-ABI call inside the running step (three streams share the "
                             "CUs); isolated_us: the same call alone on an idle GPU; trace_us: rocprofv3 kernel trace"}
+        if is_gemm:
+            roofline["mfma"] = ("v_mfma_f32_32x32x16_bf16, %d piece products per fp32 product (operands cut exactly into three bf16 pieces, "
+                                "fp32 accumulate): matrix roof = %.0f TF dense bf16 / %d per ALGORITHMIC fp32 FLOP; executed on the pipe: "
+                                "%.0f TFLOP/s" % (SPLIT_PRODUCTS, BF16_MFMA_PEAK_TFLOPS, SPLIT_PRODUCTS,
+                                                  2.0 * ints[0] * ints[1] * ints[2] / 1e12 / avg_s * SPLIT_PRODUCTS)
+                                if gemm_split else "v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain): peak = the fp32 MFMA peak")
+            roofline["hbm_bound_us"] = round(ab / 1e9 / HBM_PEAK_GBS * 1e6, 1)      # what the call's algorithmic bytes cost at the HBM peak
+            roofline["mfma_bound_us"] = round(2.0 * ints[0] * ints[1] * ints[2] / 1e12 / (BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS if gemm_split else FP32_MFMA_PEAK_TFLOPS) * 1e6, 1)
+            roofline["alg_TFLOPs"] = round(2.0 * ints[0] * ints[1] * ints[2] / 1e12 / avg_s, 1)
     # the north-star "conv gather" line: depthwise forward at (B=16, N=M=8192, C=128, r=2, K=64)
     conv_gather = None
     for (name, ints), (ms, cnt) in per.items():
@@ -807,6 +829,10 @@ def main():
                        "resident_batches": NUM_BATCHES, "event_pass_steps": ev_steps,
                        "params": nparams, "launch_mode": mode, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
                        "atan2": args.atan2,
+                       "gemm": ("split: fp32 operands as three exact bf16 pieces, six bf16-MFMA piece products accumulated in fp32 "
+                                "(error <= 2^-23 per product, the size of one fp32 rounding; tests/test_gpu_gemm_split.py); "
+                                "SPH3D_GEMM_SPLIT=0 = v_mfma_f32_32x32x2_f32" if _lib.lib().sph3d_pointwise_gemm_mode(-1)
+                                else "v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain)"),
                        "bin_ids": ("bit-identical to the reference build (same ocml atan2f; tests/test_gpu_round3.py)" if args.atan2 == "ocml"
                                    else "shared correctly-rounded atan2f: == CPU oracle, differs from the reference build within an "
                                         "ulp of a bin boundary (0.07 % of level-0 slots)"),
