@@ -34,22 +34,24 @@ def traffic(tag, pat, extra=None):
 for key, tag, pat, extra in (
         ("sph3d_depthwise_conv3d[16, 8192, 8192, 33, 128, 2, 64]", "fwd", "dwconv_fwd_multi", None),
         ("sph3d_depthwise_conv3d_grad_t[16, 8192, 8192, 33, 128, 2]", "bwd", "dwconv_bwd_t_vec<2, 4, 17", None),
-        ("sph3d_pointwise_gemm[131072, 256, 128, 0, 0]", "gemmnn", "gemm_f32_mfma", None),
-        ("sph3d_pointwise_gemm_bnstats[131072, 256, 128]", "gemmnn", "gemm_f32_mfma", None),
-        ("sph3d_pointwise_gemm_tn[32768, 1024, 128]", "gemmtn", "gemm_f32_mfma", "gemm_reduce_splits"),
-        ("sph3d_pointwise_gemm_tn[131072, 256, 128]", "gemmtn0", "gemm_f32_mfma", "gemm_reduce_splits")):
+        ("sph3d_pointwise_gemm[131072, 256, 128, 0, 0]", "gemmnn", "_mfma<", None),
+        ("sph3d_pointwise_gemm_bnstats[131072, 256, 128]", "gemmnn", "_mfma<", None),
+        ("sph3d_pointwise_gemm_tn[32768, 1024, 128]", "gemmtn", "_mfma<", "gemm_reduce_splits"),
+        ("sph3d_pointwise_gemm_tn[131072, 256, 128]", "gemmtn0", "_mfma<", "gemm_reduce_splits")):
     v = traffic(tag, pat, extra)
     if v is not None:
         t[key] = v
 
 
 def busy(tag):
-    b = avg("%s_pmc_mfma_%s.csv" % (TAG, tag), "gemm_f32_mfma", "SQ_VALU_MFMA_BUSY_CYCLES")
-    g = avg("%s_pmc_mfma_%s.csv" % (TAG, tag), "gemm_f32_mfma", "GRBM_GUI_ACTIVE")
+    b = avg("%s_pmc_mfma_%s.csv" % (TAG, tag), "_mfma<", "SQ_VALU_MFMA_BUSY_CYCLES")
+    g = avg("%s_pmc_mfma_%s.csv" % (TAG, tag), "_mfma<", "GRBM_GUI_ACTIVE")
     return round(b / (1024 * g / 8), 4) if b and g else None
 
 
 mb = t.setdefault("mfma_pipe_busy", {})
+mb["_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE/8) per launch: the fraction of the time the matrix pipe of a SIMD is busy; "
+               "v_mfma_f32_32x32x16_bf16 (split products, the default) = 32 busy cycles each, v_mfma_f32_32x32x2_f32 (SPH3D_GEMM_SPLIT=0) = 64")
 for key, tag in (("sph3d_pointwise_gemm[131072, 256, 128, 0, 0]", "nn"), ("sph3d_pointwise_gemm_bnstats[131072, 256, 128]", "nn"),
                  ("sph3d_pointwise_gemm[131072, 128, 256, 0, 1]", "nt"), ("sph3d_pointwise_gemm_tn[32768, 1024, 128]", "tn"),
                  ("sph3d_pointwise_gemm_tn[131072, 256, 128]", "tn0")):
@@ -84,13 +86,13 @@ def dur_us(path, pat):
 
 for key, tag in (("sph3d_pointwise_gemm_tn[131072, 256, 128]", "tn0"), ("sph3d_pointwise_gemm_tn[32768, 1024, 128]", "tn"),
                  ("sph3d_pointwise_gemm[131072, 256, 128, 0, 0]", "nn")):
-    a, b = dur_us("%s_pmc_mfma_%s.csv" % (TAG, tag), "gemm_f32_mfma"), dur_us("%s_pmc_mfma_%s.csv" % (TAG, tag), "gemm_reduce_splits")
+    a, b = dur_us("%s_pmc_mfma_%s.csv" % (TAG, tag), "_mfma<"), dur_us("%s_pmc_mfma_%s.csv" % (TAG, tag), "gemm_reduce_splits")
     if a is not None:
         tu[key] = round(a + (b or 0.0), 1)          # product kernel (+ slab sum) in the isolated rocprofv3 pass of that call
 t["_round"] = TAG
 missing = [k for k in ("sph3d_depthwise_conv3d[16, 8192, 8192, 33, 128, 2, 64]", "sph3d_pointwise_gemm_tn[131072, 256, 128]") if traffic(*{
     "sph3d_depthwise_conv3d[16, 8192, 8192, 33, 128, 2, 64]": ("fwd", "dwconv_fwd_multi"),
-    "sph3d_pointwise_gemm_tn[131072, 256, 128]": ("gemmtn0", "gemm_f32_mfma", "gemm_reduce_splits")}[k]) is None]
+    "sph3d_pointwise_gemm_tn[131072, 256, 128]": ("gemmtn0", "_mfma<", "gemm_reduce_splits")}[k]) is None]
 if missing:
     sys.exit("profiles/%s_pmc_* counter CSVs are missing for %s: copy the round's CSVs into profiles/ first" % (TAG, missing))
 
