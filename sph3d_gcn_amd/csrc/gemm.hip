@@ -641,6 +641,22 @@ struct SplitStage {
             }
         }
     }
+    // ragged tiles: element-wise bounds, zeros outside (rows = extent of the tile's row dimension, kdim = end of the k range)
+    __device__ __forceinline__ void load_guard(const float* __restrict__ p, int ld, int row0, int k0, int rows, int kdim, bool vec_ok)
+    {
+        if (UNITS < 256 && (int)threadIdx.x >= UNITS) return;
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int u = (int)threadIdx.x + i * 256;
+            if (KMAJ) {
+                r[i] = as_v4(load4_guard(p, ld, row0 + u / KUN, k0 + (u % KUN) * 4, rows, kdim, vec_ok));
+            } else {
+                const int kq = u % KUN, rq = u / KUN;
+                r[2 * i] = as_v4(load4_guard(p, ld, k0 + kq * 2, row0 + rq * 4, kdim, rows, vec_ok));
+                r[2 * i + 1] = as_v4(load4_guard(p, ld, k0 + kq * 2 + 1, row0 + rq * 4, kdim, rows, vec_ok));
+            }
+        }
+    }
     __device__ __forceinline__ void store(char* img) const
     {
         if (UNITS < 256 && (int)threadIdx.x >= UNITS) return;
@@ -680,7 +696,7 @@ struct SplitStage {
 #ifndef SPH3D_SPLIT_DB
 #define SPH3D_SPLIT_DB 0      // 1: two plane images (one barrier per k-tile, 3 workgroups per CU at 128 x 128); 0: one image, two barriers, 4-5 per CU
 #endif
-template <bool AK, bool BKM, int BMT, int BN, int BK, bool SPLITK, bool STATS>
+template <bool AK, bool BKM, int BMT, int BN, int BK, bool SPLITK, bool STATS, bool GUARD = false>
 __global__ __launch_bounds__(256, SPH3D_SPLIT_DB ? 2 : 4) void gemm_split_mfma(int M, int N, int Kd, const float* __restrict__ A, int lda,
                                                           const float* __restrict__ B, int ldb, float* __restrict__ Cmat, int ldc,
                                                           const float* __restrict__ bias, int act, int kchunk,
@@ -738,8 +754,15 @@ __global__ __launch_bounds__(256, SPH3D_SPLIT_DB ? 2 : 4) void gemm_split_mfma(i
     const size_t astep = AK ? (size_t)BK : (size_t)BK * lda;
     const size_t bstep = BKM ? (size_t)BK : (size_t)BK * ldb;
     const unsigned aoff = sa.lane_offset(lda), boff = sb.lane_offset(ldb);
-    sa.load(abase, lda, aoff);
-    sb.load(bbase, ldb, boff);
+    const bool a_vec = (lda % 4 == 0) && ((reinterpret_cast<size_t>(A) & 15) == 0);
+    const bool b_vec = (ldb % 4 == 0) && ((reinterpret_cast<size_t>(B) & 15) == 0);
+    if (GUARD) {
+        sa.load_guard(A, lda, m0, k_begin, M, k_end, a_vec);
+        sb.load_guard(B, ldb, n0, k_begin, N, k_end, b_vec);
+    } else {
+        sa.load(abase, lda, aoff);
+        sb.load(bbase, ldb, boff);
+    }
     sa.store(img);
     sb.store(img + PA::BYTES);
     __syncthreads();
@@ -748,10 +771,15 @@ __global__ __launch_bounds__(256, SPH3D_SPLIT_DB ? 2 : 4) void gemm_split_mfma(i
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         const bool more = (k0 + BK) < k_end;
         if (more) {                       // global -> registers for tile t+1 while tile t is multiplied
-            abase += astep;
-            bbase += bstep;
-            sa.load(abase, lda, aoff);
-            sb.load(bbase, ldb, boff);
+            if (GUARD) {
+                sa.load_guard(A, lda, m0, k0 + BK, M, k_end, a_vec);
+                sb.load_guard(B, ldb, n0, k0 + BK, N, k_end, b_vec);
+            } else {
+                abase += astep;
+                bbase += bstep;
+                sa.load(abase, lda, aoff);
+                sb.load(bbase, ldb, boff);
+            }
         }
         const char* ca = img + (DB ? buf * BUFB : 0);
         const char* cb = ca + PA::BYTES;
@@ -797,7 +825,7 @@ __global__ __launch_bounds__(256, SPH3D_SPLIT_DB ? 2 : 4) void gemm_split_mfma(i
             __syncthreads();
         }
     }
-    gemm_epilogue<BMT, BN, TM, TN, SPLITK, false, STATS, EPX, LDSF>(acc, lds, M, N, Cmat, ldc, bias, act, stats, tm, ksplit, m0, n0, wave,
+    gemm_epilogue<BMT, BN, TM, TN, SPLITK, GUARD, STATS, EPX, LDSF>(acc, lds, M, N, Cmat, ldc, bias, act, stats, tm, ksplit, m0, n0, wave,
                                                                       lane, wm, wn, li, lk);
 }
 
@@ -860,6 +888,22 @@ static void launch_gemm_tiles(int M, int N, int Kd, const float* A, int lda, con
     static const long long kMinTiles = getenv("SPH3D_GEMM_MINTILES") ? atoi(getenv("SPH3D_GEMM_MINTILES")) : 512;      // (experiments)
     // (BK = 32 at two workgroups per CU for the big grids: measured slower than BK = 16 at four, before and after the
     //  round-2 register fix: 0.101 vs 0.094 ms at (131072, 256 -> 128))
+    if constexpr (GUARD) {
+        // ragged shapes (the ModelNet plan's 35 / 67 / 131-channel layers, Cin = 3): the same kernels with element-wise bounds on the
+        // loads and stores; not for the very narrow ones (K < 16 or N < 32: mostly zero padding on the matrix pipe)
+        if (split_on() && Kd >= 16 && N >= 32) {
+            if (N > 64 && ntiles(128, 128) >= kMinTiles)
+                hipLaunchKernelGGL((gemm_split_mfma<AK, BKM, 128, 128, 16, false, false, true>), dim3(gemm_grid((M + 127) / 128, (N + 127) / 128)),
+                                   dim3(256), 0, st, M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
+            else if (!BKM && N <= 64 && ntiles(128, 64) >= kMinTiles)
+                hipLaunchKernelGGL((gemm_split_mfma<AK, BKM, 128, 64, 16, false, false, true>), dim3(gemm_grid((M + 127) / 128, (N + 63) / 64)),
+                                   dim3(256), 0, st, M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
+            else
+                hipLaunchKernelGGL((gemm_split_mfma<AK, BKM, 64, 64, 16, false, false, true>), dim3(gemm_grid((M + 63) / 64, (N + 63) / 64)), dim3(256),
+                                   0, st, M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
+            return;
+        }
+    }
     if constexpr (!GUARD) {
         if (split_on()) {
             // 64 x 64 tiles take two MFMA k-steps per barrier where K allows.  SPH3D_SPLIT_MINTILES: experiments
@@ -1054,6 +1098,13 @@ extern "C" int sph3d_pointwise_gemm_tn(int R, int Cin, int Cout, const float* X,
         else
             hipLaunchKernelGGL((gemm_split_mfma<false, false, 128, 64, 16, true, false>), dim3(gemm_grid(tiles, 1, nsplit)), dim3(256), 0, st, Cin,
                                Cout, R, X, Cin, dY, Cout, out, Cout, nullptr, 0, kchunk, nullptr, nsplit);
+    } else if (!whole && split_on() && Cin >= 32 && Cout >= 32) {
+        if (bn == 128)
+            hipLaunchKernelGGL((gemm_split_mfma<false, false, 128, 128, 16, true, false, true>), dim3(gemm_grid(tiles, 1, nsplit)), dim3(256), 0, st,
+                               Cin, Cout, R, X, Cin, dY, Cout, out, Cout, nullptr, 0, kchunk, nullptr, nsplit);
+        else
+            hipLaunchKernelGGL((gemm_split_mfma<false, false, 128, 64, 16, true, false, true>), dim3(gemm_grid(tiles, 1, nsplit)), dim3(256), 0, st,
+                               Cin, Cout, R, X, Cin, dY, Cout, out, Cout, nullptr, 0, kchunk, nullptr, nsplit);
     } else
     if (whole) { if (bn == 128) SPH3D_TN16(128); else SPH3D_TN16(64); }
     else if (bn == 128) SPH3D_TN(128, true);

@@ -11,7 +11,10 @@ pytestmark = pytest.mark.gpu
 
 SHAPES = [(131072, 128, 128), (131072, 256, 128), (32768, 256, 256), (32768, 512, 256), (12288, 512, 256), (6144, 512, 512),
           (6144, 1024, 512), (2048, 1024, 512), (6144, 2048, 256), (12288, 1024, 256), (32768, 1024, 128), (4096, 64, 128),
-          (2048, 144, 64), (1024, 48, 192)]
+          (2048, 144, 64), (1024, 48, 192),
+          # ragged shapes (element-wise bounds): the ModelNet plan's 35 / 67 / 131-channel layers and odd sizes in every dimension
+          (320000, 70, 64), (80000, 134, 128), (20000, 262, 256), (4096, 35, 67), (1000, 131, 262), (5000, 48, 200), (777, 100, 33),
+          (4100, 64, 128), (4096, 72, 96)]
 
 
 @pytest.fixture
