@@ -360,6 +360,32 @@ def isolated_call_seconds(name, ints, dev, reps=20):
         return None
 
 
+def gemm_accuracy_check(dev):
+    """the pointwise product of one mid-size layer shape in both modes of the library against float64 ON THIS BOX, before the timed
+    region: max |error| / (sum of the magnitudes of the element's terms) of the forward product, the input gradient and the weight
+    gradient — what `config.gemm` claims (fp32-sized error of the split products), measured in the same run"""
+    from sph3d_gcn_amd import tf_gemm
+    l = _lib.lib()
+    R, Ci, Co = 12288, 512, 256
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(R, Ci, device=dev, generator=g) * torch.exp2(torch.randint(-4, 4, (R, Ci), device=dev, generator=g).float())
+    w = torch.randn(Ci, Co, device=dev, generator=g) / Ci ** 0.5
+    dy = torch.randn(R, Co, device=dev, generator=g)
+    xd, wd, dyd = x.double(), w.double(), dy.double()
+    want = (xd @ wd, dyd @ wd.t(), xd.t() @ dyd)
+    mags = (xd.abs() @ wd.abs(), dyd.abs() @ wd.abs().t(), xd.abs().t() @ dyd.abs())
+    prev = l.sph3d_pointwise_gemm_mode(-1)
+    out = {"shape": [R, Ci, Co], "metric": "max |err| / sum |terms| over NN, NT, TN vs float64"}
+    try:
+        for mode, name in ((1, "split_bf16x6"), (0, "fp32_mfma")):
+            l.sph3d_pointwise_gemm_mode(mode)
+            got = (tf_gemm._pointwise_gemm_impl(x, w, False), tf_gemm._pointwise_gemm_impl(dy, w, True), tf_gemm._pointwise_gemm_tn_impl(x, dy))
+            out[name] = float("%.3g" % max(float(((a.double() - c).abs() / m).max()) for a, c, m in zip(got, want, mags)))
+    finally:
+        l.sph3d_pointwise_gemm_mode(prev)
+    return out
+
+
 def _rccl_version():
     try:
         v = torch.cuda.nccl.version()
@@ -634,6 +660,7 @@ def main():
     if args.eval:
         return eval_main(args, rank, world, dev, pinned_cpus)
 
+    gemm_check = gemm_accuracy_check(dev) if is_rank0 else None
     batches = [make_batch(rank, dev, w) for w in range(NUM_BATCHES)]
     torch.cuda.synchronize()
     ev = torch.cuda.Event()
@@ -833,6 +860,7 @@ def main():
                                 "(error <= 2^-23 per product, the size of one fp32 rounding; tests/test_gpu_gemm_split.py); "
                                 "SPH3D_GEMM_SPLIT=0 = v_mfma_f32_32x32x2_f32" if _lib.lib().sph3d_pointwise_gemm_mode(-1)
                                 else "v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain)"),
+                       "gemm_check": gemm_check,
                        "bin_ids": ("bit-identical to the reference build (same ocml atan2f; tests/test_gpu_round3.py)" if args.atan2 == "ocml"
                                    else "shared correctly-rounded atan2f: == CPU oracle, differs from the reference build within an "
                                         "ulp of a bin boundary (0.07 % of level-0 slots)"),
