@@ -397,14 +397,27 @@ constexpr int kBwdTPointsPerWG = 64;     // measured: 256 -> 1.90 ms, 128 -> 1.1
 // (SURVEY §0.5), so at S3DIS levels 0-2 only 17 of the 33 bins ever occur: 68 accumulator VGPRs instead of 132, four
 // workgroups per CU instead of three, and a 17- instead of 33-iteration segment loop.  The host cannot know the count
 // without a device->host sync, so BOTH variants are launched and each returns at once unless the count is in its range.
-template <int R, int V, int MAXF, int PARTS, bool COMPACT>
+// HUB (round 6, clouds of 32 768 points and more): on one 65 536-point cloud the first-K rule gives a few hundred low-index sources
+// thousands of in-edges each (p99 1235, maximum 11 146), and a source is one wave's sequential walk: the launch took as long as its
+// biggest hub (1.4 ms at level 0 of the ScanNet-shape plan for 4.2 M edge slots; the 16 x 8192 batch with twice the edges: 0.42).
+//   HUB = 1: this kernel, but a source with more than hubT in-edges is not walked: its grad_input row is zeroed and (slice 0)
+//            its id appended to hubList = [count, b * N + n ...];
+//   HUB = 2: the hub kernel, launched behind it on the same stream: hubW workgroups per slice; kHubGroup workgroups share a listed
+//            source, their 4 x kHubGroup waves take every (4 kHubGroup)-th 64-edge chunk of it (the chunk loop clips segments to a
+//            chunk anyway), add their grad_input partial sums with float atomics (order not fixed — as the order of a segment's
+//            entries already is not) and keep the filter gradient in their accumulators like every other wave: slabs
+//            slabBase .. slabBase + hubW - 1 of `partial`.
+//   HUB = 0 (every other launch, the headline's among them): neither — the instantiations of rounds 1-5, unchanged.
+constexpr int kHubGroup = 8;
+template <int R, int V, int MAXF, int PARTS, bool COMPACT, int HUB = 0>
 __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t_vec(
     int B, int N, int M, int F, int C, int W, int parts, int nslices,
     const int* __restrict__ offsets, const int* __restrict__ entKey, const float* __restrict__ entScale,
     const int* __restrict__ order, const int* __restrict__ activeBins, int compactMax,
     const float* __restrict__ input, const float* __restrict__ filter, const float* __restrict__ gradOutput,
     float* __restrict__ gradInput, float* __restrict__ partial,
-    const float* __restrict__ input2 = nullptr, float* __restrict__ gradInput2 = nullptr, int Ca = 0)
+    const float* __restrict__ input2 = nullptr, float* __restrict__ gradInput2 = nullptr, int Ca = 0,
+    int* __restrict__ hubList = nullptr, int hubT = 0, int slabBase = 0)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int SLW = 64 * V;                 // slice width in output channels
@@ -414,8 +427,9 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
     const int A = activeBins ? uniform(activeBins[0]) : F;
     if (COMPACT ? (A > MAXF) : (activeBins != nullptr && A <= compactMax)) return;
     // persistent workgroups: W per XCD and channel slice, all resident together (launch bounds: 3 or 4 per CU)
-    const int xcd = (int)blockIdx.x & 7;
-    const int q = (int)blockIdx.x >> 3;
+    // (HUB == 2: W workgroups per slice in all, numbered w = 0 .. W - 1; xcd is not used)
+    const int xcd = HUB == 2 ? 0 : ((int)blockIdx.x & 7);
+    const int q = HUB == 2 ? (int)blockIdx.x : ((int)blockIdx.x >> 3);
     const int slice = q / W;
     const int w = q - slice * W;
     const int slice0 = slice * SLW;
@@ -467,9 +481,11 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
     // the level-0 kernels ran 0.66 / 0.55 ms against 0.53 / 0.35 ms, with or without waiting for the atomic at once.)
     // (Also dropped: the four waves of a workgroup taking the workgroup's positions from an LDS counter — the extra live
     // scalars of the flattened (item, position) loop pushed the kernel from 119 VGPRs to 128 + 232 B of scratch: 1.16 ms.)
-    for (int item = xcd; item < B * parts; item += 8) {
-    const int b = item / parts;
-    const int pi = item - b * parts;
+    const int nhub = HUB == 2 ? uniform(hubList[0]) : 0;
+    for (int item = HUB == 2 ? w / kHubGroup : xcd; HUB == 2 ? item < nhub : item < B * parts; item += HUB == 2 ? W / kHubGroup : 8) {
+    const int hubSrc = HUB == 2 ? uniform(hubList[1 + item]) : 0;
+    const int b = HUB == 2 ? hubSrc / N : item / parts;
+    const int pi = HUB == 2 ? 0 : item - b * parts;
     // part pi = the positions pi, pi + parts, ... (parts > 1 only when B is not a multiple of 8).  Interleaved, not contiguous
     // ranges: on ONE 65 536-point cloud the first-K rule gives the low indices nearly all in-edges (median in-degree 4, p99
     // 1235, maximum 11 146), and a contiguous first eighth put them all on one XCD
@@ -478,8 +494,8 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
     const float* __restrict__ gou = gradOutput + (size_t)b * M * CR + slice0;
     const unsigned cla = (unsigned)(act ? cl0 : 0);
     const int* __restrict__ offb = offsets + (size_t)b * ((size_t)N * F + 1);
-    for (int p = pi + parts * (w * kBwdTWaves + wave); p < N; p += parts * stride) {
-        const int n = order ? uniform(order[(size_t)b * N + p]) : p;
+    for (int p = HUB == 2 ? 0 : pi + parts * (w * kBwdTWaves + wave); HUB == 2 ? p < 1 : p < N; p += HUB == 2 ? 1 : parts * stride) {
+        const int n = HUB == 2 ? hubSrc - b * N : (order ? uniform(order[(size_t)b * N + p]) : p);
         // the source's F+1 segment bounds: ONE coalesced read (lane f holds bound f), consumed with v_readlane at
         // compile-time lanes — not 33 dependent scalar loads (measured: they dominated the sparse levels)
         const int* __restrict__ o = offb + (size_t)n * F;
@@ -510,7 +526,19 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
             const int s1 = __builtin_amdgcn_ds_bpermute((fl + 1) << 2, ov0);
             nonempty = __ballot(s1 > s0);
         }
-        for (int cb = E0; cb < E1; cb += 64) {
+        if (HUB == 1 && (E1 - E0) > hubT) {
+            // a hub: left to the hub kernel (every slice's wave decides the same from the degree alone; the list holds each source once)
+            if (slice == 0 && lane == 0) hubList[1 + atomicAdd(&hubList[0], 1)] = b * N + n;
+            if (act && half == 0 && V >= R) {
+                float* gp = &gin[((size_t)b * N + n) * Cs + cin0];
+#pragma unroll
+                for (int u = 0; u < VI; u++) gp[u] = 0.f;
+            }
+            continue;
+        }
+        const int cfirst = HUB == 2 ? E0 + 64 * ((w % kHubGroup) * kBwdTWaves + wave) : E0;
+        const int cstep = HUB == 2 ? 64 * kHubGroup * kBwdTWaves : 64;
+        for (int cb = cfirst; cb < E1; cb += cstep) {
         const int cn = (E1 - cb) < 64 ? (E1 - cb) : 64;
         const int li = lane < cn ? lane : 0;
         const unsigned kel = (unsigned)entKey[cb + li] * (unsigned)CR;     // row offset in floats (M * CR < 2^32, checked by the launcher)
@@ -635,7 +663,8 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
                     float s = 0.f;
 #pragma unroll
                     for (int rr = 0; rr < R; rr++) s += gi[u * R + rr];
-                    gp[u] = s;
+                    if (HUB == 2) atomicAdd(&gp[u], s);          // the row was zeroed by the HUB == 1 launch in front of this one
+                    else gp[u] = s;
                 }
             }
         }
@@ -680,7 +709,7 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
         }
         __syncthreads();
     }
-    float* out = partial + ((size_t)xcd * W + w) * ((size_t)F * CR);
+    float* out = partial + (HUB == 2 ? (size_t)slabBase + w : (size_t)xcd * W + w) * ((size_t)F * CR);
     const unsigned long long am = COMPACT ? activeMask : ~0ull;
     for (int e = threadIdx.x; e < F * SL; e += blockDim.x) {
         const int f = e / SL;
@@ -956,13 +985,28 @@ static int bwd_slices(int F, int CR, int r)
     return (CR + 64 * V - 1) / (64 * V);
 }
 
+// hub sources (dwconv_bwd_t_vec<..., HUB>): clouds of at least 32 768 points (measured: at 16 384 the two extra launches cost more
+// than the few hubs of that level give back, profiles/r06_ab_conv_hub.log), sources with more than 1024 in-edges; kHubWG
+// workgroups per channel slice in the hub launch.  SPH3D_BWD_HUB_MIN_N / SPH3D_BWD_HUB_T: read per call (tests, experiments)
+constexpr int kHubWG = 1024;       // slabs reserved for the hub launch (its workgroup count: hub_wgs() <= kHubWG)
+static int hub_wgs()
+{
+    const char* e = getenv("SPH3D_BWD_HUB_WG");
+    int w = e ? atoi(e) : 1024;
+    w = w < kHubGroup ? kHubGroup : (w > kHubWG ? kHubWG : w);
+    return w - w % kHubGroup;
+}
+static int hub_min_n() { const char* e = getenv("SPH3D_BWD_HUB_MIN_N"); return e ? atoi(e) : 32768; }
+static int hub_threshold() { const char* e = getenv("SPH3D_BWD_HUB_T"); const int t = e ? atoi(e) : 1024; return t < 1 ? 1 : t; }
+
 extern "C" size_t sph3d_depthwise_conv3d_grad_t_workspace(int B, int N, int F, int C, int r)
 {
     int V = 0;
     if (!vec_plan(F, C * r, r, V)) return 0;
     int parts, W;
     bwd_plan(B, N, bwd_slices(F, C * r, r), 4, parts, W);      // sized for the compact variant (4 workgroups per CU)
-    return sizeof(float) * (size_t)8 * W * F * C * r;
+    // + the hub launch's slabs and the hub list (always: the size must not depend on the per-call switches)
+    return sizeof(float) * ((size_t)8 * W + kHubWG) * F * C * r + sizeof(int) * ((size_t)B * N + 4);
 }
 
 constexpr int kCompactBins = 17;     // accumulator rows of the compact variant
@@ -993,17 +1037,57 @@ static int launch_bwd_t_vec(int B, int N, int M, int F, int C, const int* offset
         if (rc) return rc;
     }
     const int* ab = compact ? active_bins : nullptr;
+    const int total = F * CR;
+    if constexpr (V == 4) {
+        if (N >= hub_min_n()) {
+            // big clouds: hub sources are left out of the sweep and shared among the waves of the hub launch (see the kernel)
+            int pc = parts;
+            if (compact) bwd_plan(B, N, nslices, 4, pc, Wc);
+            const int wmax = W > Wc ? W : Wc;
+            int* hub_list = reinterpret_cast<int*>(partial + ((size_t)8 * wmax + kHubWG) * total);
+            int rc = check_hip(hipMemsetAsync(hub_list, 0, sizeof(int), st), "conv3d grad: hub list");
+            if (rc) return rc;
+            const int T = hub_threshold();
+            const int HW = hub_wgs();
+            auto kern1 = dwconv_bwd_t_vec<R, V, MAXF, PARTS, false, 1>;
+            auto kern2 = dwconv_bwd_t_vec<R, V, MAXF, PARTS, false, 2>;
+            auto kernc1 = dwconv_bwd_t_vec<R, V, kCompactBins, PARTS, true, 1>;
+            auto kernc2 = dwconv_bwd_t_vec<R, V, kCompactBins, PARTS, true, 2>;
+            if (lds > 64 * 1024) {
+                for (const void* k : {(const void*)kern1, (const void*)kern2, (const void*)kernc1, (const void*)kernc2}) {
+                    rc = check_hip(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "conv3d: hipFuncSetAttribute");
+                    if (rc) return rc;
+                }
+            }
+            if (compact) {
+                hipLaunchKernelGGL(kernc1, dim3(8 * Wc * nslices), dim3(kBwdTWaves * 64), lds, st, B, N, M, F, C, Wc, pc, nslices, offsets, ent_key,
+                                   ent_scale, order, ab, kCompactBins, input, filter, grad_output, grad_input, partial, input2, grad_input2, Ca,
+                                   hub_list, T, 0);
+                hipLaunchKernelGGL(kernc2, dim3(HW * nslices), dim3(kBwdTWaves * 64), lds, st, B, N, M, F, C, HW, 1, nslices, offsets,
+                                   ent_key, ent_scale, order, ab, kCompactBins, input, filter, grad_output, grad_input, partial, input2,
+                                   grad_input2, Ca, hub_list, T, 8 * Wc);
+            }
+            hipLaunchKernelGGL(kern1, dim3(8 * W * nslices), dim3(kBwdTWaves * 64), lds, st, B, N, M, F, C, W, parts, nslices, offsets, ent_key,
+                               ent_scale, order, ab, kCompactBins, input, filter, grad_output, grad_input, partial, input2, grad_input2, Ca,
+                               hub_list, T, 0);
+            hipLaunchKernelGGL(kern2, dim3(HW * nslices), dim3(kBwdTWaves * 64), lds, st, B, N, M, F, C, HW, 1, nslices, offsets, ent_key,
+                               ent_scale, order, ab, kCompactBins, input, filter, grad_output, grad_input, partial, input2, grad_input2, Ca,
+                               hub_list, T, 8 * W);
+            hipLaunchKernelGGL(reduce_filter_partials, dim3((total + 31) / 32), dim3(1024), 0, st, 8 * W + HW, total, CR, partial,
+                               grad_filter, ab, kCompactBins, 8 * Wc + HW);
+            return check_launch("sph3d_depthwise_conv3d_grad_t");
+        }
+    }
     if (compact) {
         int pc;
         bwd_plan(B, N, nslices, 4, pc, Wc);
         hipLaunchKernelGGL(kernc, dim3(8 * Wc * nslices), dim3(kBwdTWaves * 64), lds, st, B, N, M, F, C,
                            Wc, pc, nslices, offsets, ent_key, ent_scale, order, ab, kCompactBins, input, filter, grad_output,
-                           grad_input, partial, input2, grad_input2, Ca);
+                           grad_input, partial, input2, grad_input2, Ca, (int*)nullptr, 0, 0);
     }
     hipLaunchKernelGGL(kern, dim3(8 * W * nslices), dim3(kBwdTWaves * 64), lds, st, B, N, M, F, C,
                        W, parts, nslices, offsets, ent_key, ent_scale, order, ab, kCompactBins, input, filter, grad_output,
-                       grad_input, partial, input2, grad_input2, Ca);
-    const int total = F * CR;
+                       grad_input, partial, input2, grad_input2, Ca, (int*)nullptr, 0, 0);
     hipLaunchKernelGGL(reduce_filter_partials, dim3((total + 31) / 32), dim3(1024), 0, st, 8 * W, total, CR, partial,
                        grad_filter, ab, kCompactBins, 8 * Wc);
     return check_launch("sph3d_depthwise_conv3d_grad_t");

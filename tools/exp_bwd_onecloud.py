@@ -36,3 +36,16 @@ for B, N, ext in ((1, 65536, (6.0, 6.0, 3.0)), (16, 8192, None)):
                                                            _lib.ptr(active), _lib.ptr(x), _lib.ptr(w), _lib.ptr(go), _lib.ptr(gi), _lib.ptr(gf), _lib.ptr(ws), wsb, _lib.stream_ptr()))
             t = timeit(call)
             print("   C %3d r %d %-15s: %8.1f us  %.1f ps/edge" % (C, r, name, t, t * 1e6 / edges), flush=True)
+        if B == 1:
+            # spatial orders (round 6): one cloud's grad_out (64 MB at C = 128) is far beyond an XCD's 4-MB L2, so WHERE consecutive
+            # sources lie decides whether a row is fetched once or by every source that lists it
+            mort = torch.empty((B, N), dtype=torch.int32, device=dev)
+            _lib.check(l.sph3d_spatial_order(B, N, _lib.ptr(xyz), _lib.ptr(mort), _lib.stream_ptr()))
+            # the kernel deals position p to XCD p % 8 (parts = 8 at B = 1): give XCD x the x-th eighth of the Morton sequence
+            reg = mort.view(8, N // 8).t().contiguous().view(1, N)
+            for name, od in (("morton order", mort), ("8 morton regions", reg)):
+                def call():
+                    _lib.check(l.sph3d_depthwise_conv3d_grad_t(B, N, N, F, C, r, _lib.ptr(offsets), _lib.ptr(ent_key), _lib.ptr(ent_scale), _lib.ptr(od),
+                                                               _lib.ptr(active), _lib.ptr(x), _lib.ptr(w), _lib.ptr(go), _lib.ptr(gi), _lib.ptr(gf), _lib.ptr(ws), wsb, _lib.stream_ptr()))
+                t = timeit(call)
+                print("   C %3d r %d %-15s: %8.1f us  %.1f ps/edge" % (C, r, name, t, t * 1e6 / edges), flush=True)
