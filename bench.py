@@ -498,7 +498,7 @@ def secondary_main(args, rank, world, dev, pinned_cpus):
     from sph3d_gcn_amd.harness import modelnet_net, shapenet_net
     name = args.config
     rng = np.random.RandomState(17 + rank)
-    s3dis_net.SAMPLING_STREAMS = args.sampling_streams or (4 if name == "scannet" else 1)
+    s3dis_net.SAMPLING_STREAMS = args.sampling_streams or (6 if name == "scannet" else 1)
     if name == "modelnet":
         per_gpu, npts = 32, 10000
         cfg = modelnet_net.modelnet_config(npts)
@@ -628,7 +628,8 @@ def main():
                          "configs 2, 3 and 5 with the same JSON contract (per-GPU batch 32 / 64 / 1, weak scaling)")
     ap.add_argument("--sampling-streams", type=int, default=0,
                     help="HIP streams the plans' sampling chains rotate over (0 = the line's default: 1 for the training lines "
-                         "whose step outweighs its sampling chain, 2 for --eval, 4 for scannet (with GPU_MAX_HW_QUEUES=8), where the chain is what a step waits for)")
+                         "whose step outweighs its sampling chain, 2 for --eval, 6 for scannet (with GPU_MAX_HW_QUEUES=8: six sampling streams + graph + main; round 6: 4 -> 6 streams "
+                         "59 -> 63 blocks/s, profiles/r06_ab_scannet_streams.log), where the chain is what a step waits for)")
     ap.add_argument("--eval", action="store_true",
                     help="SECONDARY line: forward only (is_training=False under no_grad: every separable layer is ONE kernel, "
                          "csrc/sepconv.hip) on the headline's batch; metric 'point-cloud blocks/sec (inference)'")
@@ -636,7 +637,7 @@ def main():
 
     if args.config == "scannet" or args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
         # The runtime multiplexes a process's streams onto 4 hardware queues by default, and two streams on one queue run one
-        # behind the other (tools/exp_scannet_timeline.py: a third sampling stream's chain waited for another's).  scannet: four
+        # behind the other (tools/exp_scannet_timeline.py: a third sampling stream's chain waited for another's).  scannet: six
         # sampling streams + the graph and the main stream.  Multi-rank runs: RCCL's streams come on top of the step's three,
         # and a gradient bucket's all-reduce queued behind a 1.7-ms sampling kernel would be waited for before Adam.  (One
         # GPU, three streams: 1814 blocks/s with 8 queues against 1820-1840 — left at the default there.)  The variable is read

@@ -584,7 +584,10 @@ __global__ __launch_bounds__(1024) void fps_big_kernel(int b, int n, int m, cons
 // correctness: the launcher queues fps_big_kernel behind it, gated on the error word, which recomputes every cloud's samples
 // the slow way when (and only when) the co-operative pass gave up.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kCoopP = 4;                  // points per thread
+#ifndef SPH3D_FPS_COOP_P
+#define SPH3D_FPS_COOP_P 4
+#endif
+constexpr int kCoopP = SPH3D_FPS_COOP_P;   // points per thread
 constexpr int kCoopPts = kRefBlock * kCoopP;
 #ifndef SPH3D_FPS_COOP_ERRPOLL
 #define SPH3D_FPS_COOP_ERRPOLL 0
