@@ -196,7 +196,11 @@ int sph3d_graph_transpose(int B, int N, int M, int K, int F,
                           int* offsets, int* ent_key, float* ent_scale,
                           int* active_bins /* [F+1] or NULL: count, then the ascending list of the bins that occur */,
                           void* workspace, size_t workspace_bytes, sph3d_stream_t stream);
-/* The two phases of sph3d_graph_transpose on one workspace: segment counts (also produced by sph3d_build_sphere_graph), then
+/* PACKED entries (round 6): ent_scale == NULL asks sph3d_graph_transpose[_finish[_ordered]] for entry words
+ * ent_key[e] = m | nn_count[m] << 24 and no scale array — allowed for un-weighted graphs (weight == NULL) with M <= 2^24 and K <= 255
+ * (SPH3D_EINVAL otherwise); every consumer below that takes (ent_key, ent_scale) accepts ent_scale == NULL for such a graph and
+ * derives 1 / nn_count[m] from the word (the same correctly rounded division); sph3d_max_pool3d_grad_t masks the row bits itself.
+ * The two phases of sph3d_graph_transpose on one workspace: segment counts (also produced by sph3d_build_sphere_graph), then
  * scan + fill. */
 int sph3d_graph_transpose_count(int B, int N, int M, int K, int F, const int* nn_index, const int* nn_count,
                                 const int* bin_index, int want_active, void* workspace, size_t workspace_bytes,

@@ -7,12 +7,14 @@ to the tensors it was built from, so their storage (and therefore the data_ptr i
 recycled for a different graph while the entry is alive; in-place edits are caught by the version counter.
 """
 import collections
+import os
 
 import torch
 
 from . import _lib
 
 BALANCE_MIN_POINTS = 1024   # binned graphs with at least this many source points get a degree-balanced gradient order
+PACK_ENTRIES = os.environ.get("SPH3D_TG_PACK", "1") != "0"     # (False / SPH3D_TG_PACK=0: always separate key / scale arrays)
 _MAX_ENTRIES = 24      # one S3DIS step builds 16 (8 binned intra graphs, 4 un-pooling and 4 pooling graphs); entries pin ~150 MB each at level 0
 _cache = collections.OrderedDict()
 
@@ -84,8 +86,18 @@ def _attach(nn_index, fkey, hit, nn_count, bin_index, weight):
                    0 if weight is None else weight._version))
 
 
+def entries(tg):
+    """(keys, scales) of a transposed graph returned by transpose(), decoded: int32 rows and float32 factors whether or not the
+    entries are packed (tests, tools)"""
+    _off, key, scale, _act = tg
+    if scale is not None:
+        return key, scale
+    cnt = (key >> 24) & 0xff
+    return key & 0xffffff, torch.where(cnt > 0, 1.0 / cnt.float().clamp(min=1.0), torch.zeros_like(cnt, dtype=torch.float32))
+
+
 def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1, counted_workspace=None, unique_rows=False):
-    """-> (offsets[B*(n_src*F+1)] i32, ent_key[B*M*K] i32, ent_scale[B*M*K] f32, active_bins[F+1] i32 | None) on
+    """-> (offsets[B*(n_src*F+1)] i32, ent_key[B*M*K] i32, ent_scale[B*M*K] f32 | None (packed entries: see below), active_bins[F+1] i32 | None) on
     nn_index's device; F = num_bins (the filter's bin count when bin_index is given, else 1); active_bins (count, then
     the bins that occur) is produced for binned graphs only.  counted_workspace: a transpose workspace whose counting
     phase has already run (tf_nnquery.build_sphere_graph did it inside the neighbour search): only scan + fill remain.
@@ -133,7 +145,10 @@ def transpose(nn_index, nn_count, n_src, bin_index=None, weight=None, num_bins=1
     dev = nn_index.device
     offsets = _lib.empty((B * (n_src * F + 1),), torch.int32, dev)
     ent_key = _lib.empty((B * M * K,), torch.int32, dev)
-    ent_scale = _lib.empty((B * M * K,), torch.float32, dev)
+    # un-weighted graphs with at most 2^24 rows and K <= 255: PACKED entries (include/sph3d.h) — ent_key word = m | nn_count[m] << 24,
+    # no ent_scale array (None here, NULL at the C ABI): one scattered store per edge in the fill pass instead of two
+    packed = weight is None and M <= (1 << 24) and K <= 255 and PACK_ENTRIES
+    ent_scale = None if packed else _lib.empty((B * M * K,), torch.float32, dev)
     active = _lib.empty((F + 1,), torch.int32, dev) if bin_index is not None else None
     l = _lib.lib()
     wsb = l.sph3d_graph_transpose_workspace(B, n_src, M, K, F)

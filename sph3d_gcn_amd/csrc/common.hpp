@@ -74,8 +74,18 @@ static inline TgWs tg_ws(void* workspace, int B, int N, int M, int K, int F)
     return w;
 }
 
+// ---- packed entries of the transposed graph (round 6) ----------------------------------------------------------------------------
+// ent_scale == NULL: an entry word of ent_key is  m | nn_count[m] << 24  (un-weighted graphs with at most 2^24 rows and K <= 255):
+// the fill pass then makes ONE scattered 4-byte store per edge instead of two, and a consumer takes the row and its 1 / count
+// (the same correctly rounded division the fill pass would have done) from one word.
+constexpr unsigned kTgKeyMask = 0x00ffffffu;
+static inline bool tg_packable(int M, int K, const void* weight) { return weight == nullptr && M <= (1 << 24) && K <= 255; }
+
 // ---- device helpers -----------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ int tg_key(int word, bool packed) { return packed ? (int)((unsigned)word & kTgKeyMask) : word; }
+__device__ __forceinline__ float tg_packed_scale(int word) { return 1.0f / (float)((unsigned)word >> 24); }
 
 // number of set bits of `mask` strictly below this lane
 __device__ __forceinline__ int prefix_popc(unsigned long long mask)

@@ -541,8 +541,10 @@ __global__ __launch_bounds__(kBwdTWaves * 64, COMPACT ? 4 : 3) void dwconv_bwd_t
         for (int cb = cfirst; cb < E1; cb += cstep) {
         const int cn = (E1 - cb) < 64 ? (E1 - cb) : 64;
         const int li = lane < cn ? lane : 0;
-        const unsigned kel = (unsigned)entKey[cb + li] * (unsigned)CR;     // row offset in floats (M * CR < 2^32, checked by the launcher)
-        const float svl = entScale[cb + li];
+        // (entScale == NULL: packed entries, common.hpp: row and count in one word, 1 / count divided here: once per lane and chunk)
+        const int wkey = entKey[cb + li];
+        const unsigned kel = (unsigned)tg_key(wkey, entScale == nullptr) * (unsigned)CR;     // row offset in floats (M * CR < 2^32, checked by the launcher)
+        const float svl = entScale == nullptr ? tg_packed_scale(wkey) : entScale[cb + li];
         const float sv = lane < cn ? svl : 0.f;
 #pragma unroll
         for (int fi = 0; fi < MAXF; fi++) {
@@ -800,7 +802,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_t_generic(
                     const int cout = cin * r + rr;
                     float sg = 0.f;
                     for (int e = e0; e < e1; e++)
-                        sg = fmaf(gradOutput[((size_t)b * M + entKey[e]) * CR + cout], entScale[e], sg);
+                        sg = fmaf(gradOutput[((size_t)b * M + tg_key(entKey[e], entScale == nullptr)) * CR + cout],
+                                  entScale == nullptr ? tg_packed_scale(entKey[e]) : entScale[e], sg);
                     gi = fmaf(sg, filter[(size_t)f * CR + cout], gi);
                     unsafeAtomicAdd(&gtab[f * SW + cl * r + rr], sg * x);     // one LDS atomic per (segment, channel)
                 }

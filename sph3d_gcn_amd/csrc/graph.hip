@@ -208,8 +208,12 @@ __device__ __forceinline__ void tg_fill_rows(int fb, int nfb, int B, int N, int 
             int f = binIndex ? binIndex[e] : 0;
             f = f < 0 ? 0 : (f >= F ? F - 1 : f);
             const int dst = ob[(size_t)n * F + f] + slotPos[e];
-            entKey[dst] = m;
-            entScale[dst] = weight ? weight[e] : inv;
+            if (entScale == nullptr) {
+                entKey[dst] = m | (cnt << 24);              // packed entry (common.hpp): one scattered store per edge
+            } else {
+                entKey[dst] = m;
+                entScale[dst] = weight ? weight[e] : inv;
+            }
         }
     }
 }
@@ -448,6 +452,8 @@ static int tg_finish(int B, int N, int M, int K, int F, const int* nn_index, con
 {
     int rc = tg_dims_ok(B, N, M, K, F, bin_index, workspace, workspace_bytes);
     if (rc || B == 0) return rc;
+    SPH3D_REQUIRE(ent_scale != nullptr || tg_packable(M, K, weight),
+                  "graph_transpose: ent_scale == NULL (packed entries) needs an un-weighted graph with M <= 2^24 and K <= 255 (M=%d K=%d)", M, K);
     hipStream_t st = as_stream(stream);
     const TgWs w = tg_ws(workspace, B, N, M, K, F);
     const long long total = (long long)B * M * K;

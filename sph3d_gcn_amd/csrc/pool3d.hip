@@ -209,8 +209,9 @@ __global__ __launch_bounds__(256) void gather_bwd_t(
             for (int v = 0; v < V; v++) acc[v] = 0.f;
 #pragma unroll 8
             for (int e = e0; e < e1; e++) {
-                const int m = entKey[e];
-                const float sc = entScale[e];
+                const int wk = entKey[e];
+                const int m = tg_key(wk, entScale == nullptr);          // (packed entries: common.hpp)
+                const float sc = entScale == nullptr ? tg_packed_scale(wk) : entScale[e];
                 {   // branch-free: inactive lanes read channel 0
                     if (V == 4) {
                         const float4 t = *reinterpret_cast<const float4*>(&gob[(size_t)m * C + cc]);
@@ -299,7 +300,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_t(
                 }
             };
 #pragma unroll 4
-            for (int e = e0; e < e1; e++) take(entKey[e]);
+            // (an entry word may be packed with the row's count above bit 24: common.hpp; rows are < 2^24 whenever it is)
+            for (int e = e0; e < e1; e++) take(Mout <= (1 << 24) ? (int)((unsigned)entKey[e] & kTgKeyMask) : entKey[e]);
             if (n == 0) {                  // rows without neighbours: maxIndex 0 (see above); 64 rows per trip
                 for (int m0 = 0; m0 < Mout; m0 += 64) {
                     const int mm = m0 + lane;
@@ -356,8 +358,10 @@ __global__ __launch_bounds__(256) void gather_bwd_t_split(
 #pragma unroll 4
             for (int e = e0 + 2 * wave; e < e1; e += 8) {
                 const bool two = (e + 1) < e1;                           // wave-uniform
-                const int m0 = entKey[e], m1 = entKey[two ? e + 1 : e];
-                const float s0 = entScale[e], s1 = two ? entScale[e + 1] : 0.f;
+                const int w0 = entKey[e], w1 = entKey[two ? e + 1 : e];
+                const bool pk = entScale == nullptr;
+                const int m0 = tg_key(w0, pk), m1 = tg_key(w1, pk);
+                const float s0 = pk ? tg_packed_scale(w0) : entScale[e], s1 = two ? (pk ? tg_packed_scale(w1) : entScale[e + 1]) : 0.f;
                 const int m = half ? m1 : m0;
                 const float sc = half ? s1 : s0;
                 const float4 t = *reinterpret_cast<const float4*>(&gob[(size_t)m * C + cch]);
@@ -371,8 +375,9 @@ __global__ __launch_bounds__(256) void gather_bwd_t_split(
         } else
 #pragma unroll 4
         for (int e = e0 + wave; e < e1; e += 4) {
-            const int m = entKey[e];
-            const float sc = entScale[e];
+            const int wk = entKey[e];
+            const int m = tg_key(wk, entScale == nullptr);
+            const float sc = entScale == nullptr ? tg_packed_scale(wk) : entScale[e];
             if (V == 4) {
                 const float4 t = *reinterpret_cast<const float4*>(&gob[(size_t)m * C + cc]);
                 acc[0] = fmaf(t.x, sc, acc[0]);

@@ -153,8 +153,10 @@ def test_fused_graph_construction_equals_separate_ops(dev, case):
         i2, c2, d2, f2 = tf_nnquery.build_sphere_graph(xyz, radius, K, kernel)
         assert torch.equal(i2, idx) and torch.equal(c2, cnt) and torch.equal(d2.view(torch.int32), dst.view(torch.int32))
         assert torch.equal(f2, filt)
-        off_a, key_a, sc_a, act_a = _tgraph.transpose(idx, cnt, N, bin_index=filt, num_bins=F)
-        off_b, key_b, sc_b, act_b = _tgraph.transpose(i2, c2, N, bin_index=f2, num_bins=F)      # cached by the fused op
+        tg_a = _tgraph.transpose(idx, cnt, N, bin_index=filt, num_bins=F)
+        tg_b = _tgraph.transpose(i2, c2, N, bin_index=f2, num_bins=F)      # cached by the fused op
+        off_a, act_a, off_b, act_b = tg_a[0], tg_a[3], tg_b[0], tg_b[3]
+        (key_a, sc_a), (key_b, sc_b) = _tgraph.entries(tg_a), _tgraph.entries(tg_b)       # (decoded: the entries may be packed)
         assert torch.equal(off_a, off_b) and torch.equal(act_a[:1 + int(act_a[0])], act_b[:1 + int(act_b[0])])
         oa, ka, kb = _n(off_a), _n(key_a), _n(key_b)
         sa, sb = _n(sc_a), _n(sc_b)
@@ -823,10 +825,12 @@ def test_counted_inter_level_search_equals_separate_calls(dev):
     db = torch.rand((B, N, 3), generator=g).to(dev)
     qr = torch.rand((B, M, 3), generator=g).to(dev)
     i0, c0, d0 = tf_nnquery.build_sphere_neighbor(db, qr, 0.12, None, K)
-    t0 = [t.clone() for t in _tgraph.transpose(i0, c0, N)[:3]]
+    tg0 = _tgraph.transpose(i0, c0, N)
+    t0 = [tg0[0].clone()] + [t.clone() for t in _tgraph.entries(tg0)]
     i1, c1, d1 = tf_nnquery.build_sphere_neighbor_counted(db, qr, 0.12, K)
     assert torch.equal(i0, i1) and torch.equal(c0, c1) and torch.equal(d0, d1)
-    t1 = _tgraph.transpose(i1, c1, N)[:3]          # cached by the counted call
+    tg1 = _tgraph.transpose(i1, c1, N)          # cached by the counted call
+    t1 = [tg1[0]] + list(_tgraph.entries(tg1))
     assert torch.equal(t0[0], t1[0])               # offsets
     # entries of one source point may be filled in any order: compare them as sorted (key, scale) pairs per segment
     off = t0[0].view(B, N + 1).cpu()

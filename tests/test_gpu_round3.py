@@ -72,7 +72,9 @@ def test_fused_graph_kernel_vs_oracle_directly(dev, case, kernel):
     np.testing.assert_array_equal(_n(filt), filt_o)
     # the transposed graph it cached: per (source, bin) segment the multiset of (target, 1/count) of the oracle's graph
     F = kernel[0] * kernel[1] * kernel[2] + 1
-    off, key, scale, act = _tgraph.transpose(idx, cnt, N, bin_index=filt, num_bins=F)
+    tg = _tgraph.transpose(idx, cnt, N, bin_index=filt, num_bins=F)
+    off, act = tg[0], tg[3]
+    key, scale = _tgraph.entries(tg)                # (decoded: the entries may be packed)
     off_n, key_n = _n(off), _n(key)
     L = N * F
     valid = np.arange(K)[None, None, :] < cnt_o[:, :, None]
