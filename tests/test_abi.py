@@ -71,6 +71,36 @@ def test_search_entry_points_with_caller_workspace():
     assert l.sph3d_build_sphere_neighbor_workspace(16, 8192, 2048) < need
 
 
+def test_round6_entry_points_validate_on_the_host():
+    """the entry points added in round 6 answer their shape questions and reject bad requests before any launch"""
+    import ctypes
+    import torch
+    from sph3d_gcn_amd import _lib, _tgraph
+    l = _lib.lib()
+    # training-mode one-kernel layer: C <= 128, C * r <= 256, Cout a power of two <= 256; statistics rows per launch
+    assert l.sph3d_separable_conv3d_train_supported(8192, 33, 128, 2, 64, 128) == 1
+    assert l.sph3d_separable_conv3d_train_supported(8192, 33, 256, 2, 64, 128) == 0
+    assert l.sph3d_separable_conv3d_train_supported(8192, 33, 64, 2, 64, 96) == 0
+    assert l.sph3d_separable_conv3d_train_blocks(128) == 512 and l.sph3d_separable_conv3d_train_blocks(256) == 256
+    assert l.sph3d_separable_conv3d_train_blocks(96) == 0
+    rc = l.sph3d_separable_conv3d_train(1, 64, 64, 33, 256, 2, 16, 128, None, None, None, None, None, None, None, None, None, None, None)
+    assert rc == -4 and b"not covered" in l.sph3d_last_error()               # SPH3D_EUNSUPPORTED
+    # product mode: query (-1) leaves it alone; the default is the split-bf16 form unless the environment says otherwise
+    cur = l.sph3d_pointwise_gemm_mode(-1)
+    assert cur in (0, 1) and l.sph3d_pointwise_gemm_mode(-1) == cur
+    # packed transposed-graph entries need an un-weighted graph with K <= 255 (checked after the workspace)
+    ws = ctypes.create_string_buffer(l.sph3d_graph_transpose_workspace(1, 8, 8, 300, 1))
+    rc = l.sph3d_graph_transpose_finish(1, 8, 8, 300, 1, None, None, None, None, None, None, None, None, ctypes.cast(ws, ctypes.c_void_p),
+                                        len(ws), None)
+    assert rc == -1 and b"packed entries" in l.sph3d_last_error()
+    # decoding of packed entries (tests / tools): row in the low 24 bits, 1 / count from the byte above
+    key = torch.tensor([5 | (4 << 24), 70000 | (64 << 24), 0], dtype=torch.int32)
+    k, s = _tgraph.entries((None, key, None, None))
+    assert k.tolist() == [5, 70000, 0] and s.tolist() == [0.25, 1.0 / 64, 0.0]
+    k2, s2 = _tgraph.entries((None, key, torch.ones(3), None))
+    assert k2 is key and s2.tolist() == [1.0, 1.0, 1.0]
+
+
 def test_library_default_bins_are_the_reference_builds():
     """tf_buildkernel's library-wide default is the device-library atan2f (= the reference build, bit for bit); the tests run in
     "shared" mode through conftest's fixture"""
