@@ -209,6 +209,13 @@ int sph3d_graph_transpose_finish(int B, int N, int M, int K, int F,
                                  const int* nn_index, const int* nn_count, const int* bin_index,
                                  const float* weight, int* offsets, int* ent_key, float* ent_scale, int* active_bins,
                                  void* workspace, size_t workspace_bytes, sph3d_stream_t stream);
+/* The pooling graph of a level = the rows of its intra-level graph at the sampled points (the two tf.gather_nd of
+ * models/SPH3D_s3dis.py:68-72) in ONE launch that, with a transpose workspace (sph3d_graph_transpose_workspace(B, N, S, K, 1) bytes;
+ * NULL: copy only), also runs the counting phase of the pooling graph's transposed graph (finish it with
+ * sph3d_graph_transpose_finish[_ordered]).  pairs[B*S][2] = (cloud, point); out_index [B, S, K], out_count [B, S]. */
+int sph3d_gather_rows_count(int B, int N, int S, int K, const int* pairs, const int* nn_index, const int* nn_count,
+                            int* out_index, int* out_count, void* transpose_workspace, size_t transpose_workspace_bytes,
+                            sph3d_stream_t stream);
 /* sph3d_graph_transpose_finish that also writes sph3d_graph_balanced_order's permutation (order[B*N]; NULL: none) from inside its
  * fill launch: scan (one pass) + fill/order = two launches per graph. */
 int sph3d_graph_transpose_finish_ordered(int B, int N, int M, int K, int F,

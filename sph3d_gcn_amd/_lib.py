@@ -45,6 +45,7 @@ SIGNATURES = {
     "sph3d_avg_pool3d_grad": (_I, [_I] * 5 + [_P] * 4 + [_P, _S, _P]),
     "sph3d_graph_balanced_order": (_I, [_I, _I, _I, _P, _P, _P]),
     "sph3d_gather_nd": (_I, [_I, _I, ctypes.c_longlong, _I, _P, _P, _P, _P]),
+    "sph3d_gather_rows_count": (_I, [_I] * 4 + [_P] * 5 + [_P, _S, _P]),
     "sph3d_graph_transpose_workspace": (_S, [_I] * 5),
     "sph3d_graph_transpose": (_I, [_I] * 5 + [_P] * 8 + [_P, _S, _P]),
     "sph3d_graph_transpose_count": (_I, [_I] * 5 + [_P] * 3 + [_I, _P, _S, _P]),

@@ -526,6 +526,59 @@ extern "C" int sph3d_gather_nd(int B, int N, long long S, int row, const int* pa
     return check_launch("sph3d_gather_nd");
 }
 
+// The pooling graph of a level is the rows of its intra-level graph at the sampled points (models/SPH3D_s3dis.py:68-72: two
+// tf.gather_nd, one of nn_index and one of nn_count); its transposed graph serves the max-pool gradient.  One kernel: a wave per
+// sampled row copies the row and its count and counts the in-edges of every neighbour it lists (the first pass of
+// sph3d_graph_transpose, F = 1: same counters / slot positions in the same workspace layout) — three launches and a second read of
+// the gathered rows fewer per pooling graph.
+__global__ __launch_bounds__(256) void gather_rows_count_kernel(int B, int N, int S, int K, const int* __restrict__ pairs,
+                                                                const int* __restrict__ nnIndex, const int* __restrict__ nnCount,
+                                                                int* __restrict__ outIndex, int* __restrict__ outCount,
+                                                                int* __restrict__ deg, int* __restrict__ slotPos)
+{
+    const int lane = (int)threadIdx.x & 63;
+    const long long rows = (long long)B * S;
+    for (long long s = (long long)blockIdx.x * 4 + ((int)threadIdx.x >> 6); s < rows; s += (long long)gridDim.x * 4) {
+        int b = pairs[s * 2], p = pairs[s * 2 + 1];
+        b = b < 0 ? 0 : (b >= B ? B - 1 : b);              // out-of-range pairs are clamped (as sph3d_gather_nd)
+        p = p < 0 ? 0 : (p >= N ? N - 1 : p);
+        const int ob = (int)(s / S);                        // the cloud the OUTPUT row belongs to (its transposed graph's cloud)
+        const long long src = ((long long)b * N + p);
+        const int cnt = nnCount[src];
+        if (lane == 0) outCount[s] = cnt;
+        for (int k = lane; k < K; k += 64) {
+            const int id = nnIndex[src * K + k];
+            outIndex[s * K + k] = id;
+            if (deg != nullptr && k < cnt) slotPos[s * K + k] = atomicAdd(&deg[(size_t)ob * N + (id < 0 ? 0 : (id >= N ? N - 1 : id))], 1);
+        }
+    }
+}
+
+extern "C" int sph3d_gather_rows_count(int B, int N, int S, int K, const int* pairs, const int* nn_index, const int* nn_count,
+                                       int* out_index, int* out_count, void* transpose_workspace, size_t transpose_workspace_bytes,
+                                       sph3d_stream_t stream)
+{
+    SPH3D_REQUIRE(B > 0 && N > 0 && S >= 0 && K > 0, "gather_rows_count: bad dims B=%d N=%d S=%d K=%d", B, N, S, K);
+    if (S == 0) return SPH3D_OK;
+    hipStream_t st = as_stream(stream);
+    int* deg = nullptr;
+    int* slot = nullptr;
+    if (transpose_workspace != nullptr) {
+        int rc = tg_dims_ok(B, N, S, K, 1, nullptr, transpose_workspace, transpose_workspace_bytes);
+        if (rc) return rc;
+        const TgWs w = tg_ws(transpose_workspace, B, N, S, K, 1);
+        rc = zero_async(w.deg, sizeof(int) * w.zero_words, st, "gather_rows_count: memset");
+        if (rc) return rc;
+        deg = w.deg;
+        slot = w.slot_pos;
+    }
+    long long blocks = ((long long)B * S + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(gather_rows_count_kernel, dim3((unsigned)blocks), dim3(256), 0, st, B, N, S, K, pairs, nn_index, nn_count, out_index,
+                       out_count, deg, slot);
+    return check_launch("sph3d_gather_rows_count");
+}
+
 extern "C" int sph3d_graph_transpose(int B, int N, int M, int K, int F,
                                      const int* nn_index, const int* nn_count, const int* bin_index,
                                      const float* weight, int* offsets, int* ent_key, float* ent_scale, int* active_bins,

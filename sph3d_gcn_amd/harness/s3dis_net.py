@@ -6,6 +6,7 @@ the same sequence of s3g_util calls, with the same shapes, as the reference's mo
 The config mirrors s3dis_seg/s3dis_config.py:3-26.
 """
 import copy
+import os
 import types
 
 import torch
@@ -92,6 +93,7 @@ _side_stream = {}
 # what a step waits for: the forward-only loop (2: 3.51 -> 3.33 ms) and the 65 536-point plan (2: 53.4 -> 29.7 ms).
 SAMPLING_STREAMS = 1
 _USE_ARENA = True          # one allocation per plan and producing stream (GraphPlan)
+FUSE_POOL_GRAPH = os.environ.get("SPH3D_FUSE_POOL_GRAPH", "1") != "0"     # pooling rows + counts + transpose count pass in one launch
 _ARENA_NEED = {}           # (points shape, config, ...) -> bytes the sampling / graph stream's tensors of such a plan took
 
 
@@ -264,6 +266,12 @@ class GraphPlan:
         return {} if self.need_backward else {"with_transpose": False}
 
     def _make_pool(self, l, g):
+        fused = getattr(s3g_util, "gather_pooling_graph", None)        # (the oracle-backed CPU stand-ins of the tests have none)
+        if fused is not None and g["intra_idx"].is_cuda and FUSE_POOL_GRAPH:
+            # both gathers + (max pooling, training) the counting pass of the pooling graph's transpose in one launch
+            g["inter_idx"], g["inter_cnt"] = fused(g["intra_idx"], g["intra_cnt"], self.indices[l],
+                                                   with_transpose=self.config.pool_method == 'max' and self.need_backward)
+            return
         g["inter_idx"] = s3g_util.gather_nd(g["intra_idx"], self.indices[l])       # models/SPH3D_s3dis.py:68-72
         g["inter_cnt"] = s3g_util.gather_nd(g["intra_cnt"], self.indices[l])
         if self.config.pool_method == 'max' and g["inter_idx"].is_cuda and self.need_backward:

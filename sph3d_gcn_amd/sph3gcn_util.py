@@ -246,6 +246,33 @@ def gather_nd(params, indices):
     return params[b, p]
 
 
+def gather_pooling_graph(nn_index, nn_count, indices, with_transpose=True):
+    """(gather_nd(nn_index, indices), gather_nd(nn_count, indices)) — the pooling graph of models/SPH3D_s3dis.py:68-72 — as ONE
+    launch on the HIP device which (with_transpose) also counts the in-edges of the pooling graph's transpose, finished and cached
+    here for the max-pool gradient (tf_pool3d).  Same two tensors as the two gather_nd calls."""
+    if not (nn_index.is_cuda and nn_index.dim() == 3 and nn_count.dim() == 2 and indices.dtype == torch.int32 and indices.shape[-1] == 2
+            and indices.shape[0] == nn_index.shape[0]):
+        return gather_nd(nn_index, indices), gather_nd(nn_count, indices)
+    from . import _tgraph
+    nn_index, nn_count, indices = nn_index.contiguous(), nn_count.contiguous(), indices.contiguous()
+    B, N, K = nn_index.shape
+    S = indices.shape[1]
+    dev = nn_index.device
+    out_idx = _lib.empty((B, S, K), torch.int32, dev)
+    out_cnt = _lib.empty((B, S), torch.int32, dev)
+    l = _lib.lib()
+    ws, wsb = None, 0
+    if with_transpose:
+        wsb = l.sph3d_graph_transpose_workspace(B, N, S, K, 1)
+        ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=dev)
+    _lib.check(l.sph3d_gather_rows_count(B, N, S, K, _lib.ptr(indices), _lib.ptr(nn_index), _lib.ptr(nn_count), _lib.ptr(out_idx),
+                                         _lib.ptr(out_cnt), _lib.ptr(ws), wsb, _lib.stream_ptr()))
+    if with_transpose:
+        # (rows gathered from the ball query's rows: ascending, distinct neighbour ids)
+        _tgraph.transpose(out_idx, out_cnt, N, counted_workspace=ws, unique_rows=True)
+    return out_idx, out_cnt
+
+
 # --------------------------------------------------------------------------------------
 # layers (utils/sph3gcn_util.py:88-273)
 # --------------------------------------------------------------------------------------
