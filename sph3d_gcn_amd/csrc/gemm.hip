@@ -614,6 +614,15 @@ struct SplitStage {
     static constexpr int KG = BK / 8;                       // k-groups of 8
     static constexpr int PLANE = KG * BT * 16;              // bytes of one piece's plane
     static constexpr int BYTES = 3 * PLANE;
+    // 16-byte slot of (k-group g, row): the row index XOR-ed with a few bits of (g, row bit 4), constant over the 16 consecutive rows
+    // a fragment read covers (it stays a permutation of one 256-byte bank group: conflict-free), different for the writers that
+    // would otherwise meet in a bank — the two k-groups of a k-contiguous unit's store (same row) and, for the row-contiguous
+    // operands, the rows 16 apart and the two k-groups of one 4-byte store (4-way conflicts before:
+    // profiles/r06_pmc_gemm_split_nn_vs_nt_6144x2048x256.log, 14 M against 2.4 M conflict cycles)
+    __device__ __forceinline__ static int slot(int g, int row)
+    {
+        return (g * BT + row) ^ (((row >> 4) & 1) | ((g & 1) << 1) | ((g & 1) << 3) | (((g >> 1) & 1) << 2));
+    }
     static constexpr int KUN = KMAJ ? BK / 4 : BK / 2;      // units along k
     static constexpr int UNITS = KMAJ ? BT * (BK / 4) : (BT / 4) * (BK / 2);
     static constexpr int NCH = (UNITS + 255) / 256;
@@ -667,21 +676,21 @@ struct SplitStage {
                 const int row = u / KUN, kq = u % KUN;                  // k = 4 kq .. 4 kq + 3 of `row`
                 const f32x4 v = r[i];
                 const Split3 p0 = split_pair(v.x, v.y), p1 = split_pair(v.z, v.w);
-                char* q = img + (((kq >> 1) * BT + row) << 4) + ((kq & 1) << 3);
+                char* q = img + (slot(kq >> 1, row) << 4) + ((kq & 1) << 3);
                 *reinterpret_cast<u32x2v*>(q) = u32x2v{p0.h, p1.h};
                 *reinterpret_cast<u32x2v*>(q + PLANE) = u32x2v{p0.m, p1.m};
                 *reinterpret_cast<u32x2v*>(q + 2 * PLANE) = u32x2v{p0.l, p1.l};
             } else {
                 const int kq = u % KUN, rq = u / KUN;                   // k = 2 kq, 2 kq + 1 of rows 4 rq .. 4 rq + 3
                 const int k0 = kq * 2;
-                char* q = img + (((k0 >> 3) * BT + rq * 4) << 4) + ((k0 & 7) << 1);
                 const f32x4 a = r[2 * i], b = r[2 * i + 1];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const Split3 sp = split_pair(a[j], b[j]);
-                    *reinterpret_cast<unsigned*>(q + j * 16) = sp.h;
-                    *reinterpret_cast<unsigned*>(q + j * 16 + PLANE) = sp.m;
-                    *reinterpret_cast<unsigned*>(q + j * 16 + 2 * PLANE) = sp.l;
+                    char* q = img + (slot(k0 >> 3, rq * 4 + j) << 4) + ((k0 & 7) << 1);
+                    *reinterpret_cast<unsigned*>(q) = sp.h;
+                    *reinterpret_cast<unsigned*>(q + PLANE) = sp.m;
+                    *reinterpret_cast<unsigned*>(q + 2 * PLANE) = sp.l;
                 }
             }
         }
@@ -689,7 +698,7 @@ struct SplitStage {
     // piece `pc` of the lane's operand: tile row `row`, k-group g
     __device__ __forceinline__ static bf16x8 frag(const char* img, int pc, int row, int g)
     {
-        return *reinterpret_cast<const bf16x8*>(img + pc * PLANE + ((g * BT + row) << 4));
+        return *reinterpret_cast<const bf16x8*>(img + pc * PLANE + (slot(g, row) << 4));
     }
 };
 
