@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <utility>
 #include "../../include/sph3d.h"
@@ -28,10 +29,13 @@ void set_error(const char* fmt, ...)
 namespace {
 struct Scratch { void* p; size_t bytes; };
 std::mutex g_scratch_mu;
-std::map<std::pair<int, hipStream_t>, Scratch> g_scratch;
+std::map<std::tuple<int, hipStream_t, int>, Scratch> g_scratch;
 }  // namespace
 
-void* stream_scratch(hipStream_t stream, size_t bytes)
+// kind 0: plain scratch (no state between calls).  kind 1: zero-initialised when (re)allocated, and every kernel that uses it
+// leaves its first 16 KB zero again (the arrival counters of the in-kernel split-K exchange, gemm.hip): state that survives
+// from call to call on the stream, so it has its own buffer.
+void* stream_scratch(hipStream_t stream, size_t bytes, int kind)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) {
@@ -41,7 +45,7 @@ void* stream_scratch(hipStream_t stream, size_t bytes)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
     std::lock_guard<std::mutex> lk(g_scratch_mu);
-    Scratch& s = g_scratch[std::make_pair(dev, stream)];
+    Scratch& s = g_scratch[std::make_tuple(dev, stream, kind)];
     if (s.bytes >= bytes && s.p != nullptr) return s.p;
     if (cap != hipStreamCaptureStatusNone) return nullptr;      // no hipMalloc / hipFree while a graph is being captured
     if (s.p != nullptr) {
@@ -53,6 +57,11 @@ void* stream_scratch(hipStream_t stream, size_t bytes)
     void* p = nullptr;
     if (hipMalloc(&p, want) != hipSuccess) {
         (void)hipGetLastError();
+        return nullptr;
+    }
+    if (kind == 1 && hipMemset(p, 0, want) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(p);
         return nullptr;
     }
     s.p = p;
@@ -71,7 +80,7 @@ int release_scratch(hipStream_t stream, bool all_streams)
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     int n = 0;
     for (auto it = g_scratch.begin(); it != g_scratch.end();) {
-        if (it->first.first == dev && (all_streams || it->first.second == stream)) {
+        if (std::get<0>(it->first) == dev && (all_streams || std::get<1>(it->first) == stream)) {
             if (it->second.p != nullptr) {
                 (void)hipFree(it->second.p);
                 n++;

@@ -32,6 +32,12 @@ static inline int check_launch(const char* what)
     return SPH3D_OK;
 }
 
+// api.cpp: a library-owned device buffer of at least `bytes` for work queued on `stream` of the current device (one per
+// (device, stream, kind), grown on demand and kept; nullptr if the allocation fails or the stream is being captured).
+// kind 0: only for state that is dead when the call's last kernel has run.  kind 1: zero-initialised; its users leave the
+// first 16 KB zero (arrival counters, gemm.hip)
+void* stream_scratch(hipStream_t stream, size_t bytes, int kind = 0);
+
 static inline int check_hip(hipError_t e, const char* what)
 {
     if (e != hipSuccess) {

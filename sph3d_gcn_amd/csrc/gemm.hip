@@ -705,12 +705,20 @@ struct SplitStage {
 #ifndef SPH3D_SPLIT_DB
 #define SPH3D_SPLIT_DB 0      // 1: two plane images (one barrier per k-tile, 3 workgroups per CU at 128 x 128); 0: one image, two barriers, 4-5 per CU
 #endif
-template <bool AK, bool BKM, int BMT, int BN, int BK, bool SPLITK, bool STATS, bool GUARD = false>
+// XS (in-kernel split-K exchange, for products whose tile grid is too small to fill the chip and whose k loop is long): the grid holds
+// `nsplit` workgroups per tile, each multiplying `kchunk` of k.  Splits 1 .. nsplit-1 (the LOWER workgroup ids: dispatched first,
+// they never wait) store their accumulators — in register layout, 16 contiguous bytes per lane — to their slab of `xslab`, fence,
+// and count themselves in at xflag[tile]; split 0 (dispatched last) waits for the count, adds the slabs in split order
+// (deterministic), clears the counter and runs the ordinary epilogue (bias / ELU / BN statistics / float4 rows).  No slab-sum
+// launch, no float atomics.
+template <bool AK, bool BKM, int BMT, int BN, int BK, bool SPLITK, bool STATS, bool GUARD = false, bool XS = false>
 __global__ __launch_bounds__(256, SPH3D_SPLIT_DB ? 2 : 4) void gemm_split_mfma(int M, int N, int Kd, const float* __restrict__ A, int lda,
                                                           const float* __restrict__ B, int ldb, float* __restrict__ Cmat, int ldc,
                                                           const float* __restrict__ bias, int act, int kchunk,
-                                                          float* __restrict__ stats = nullptr, int nsplit = 1)
+                                                          float* __restrict__ stats = nullptr, int nsplit = 1,
+                                                          float* __restrict__ xslab = nullptr, int* __restrict__ xflag = nullptr)
 {
+    static_assert(!(XS && SPLITK) && !(XS && GUARD), "the exchange variant is an unguarded, non-slab kernel");
     using PA = SplitStage<AK, BMT, BK>;
     using PB = SplitStage<BKM, BN, BK>;
     constexpr int WM = BMT / 2, WN = BN / 2;     // wave sub-tile
@@ -727,7 +735,15 @@ __global__ __launch_bounds__(256, SPH3D_SPLIT_DB ? 2 : 4) void gemm_split_mfma(i
     const int tiles_m = (M + BMT - 1) / BMT;
     const int wg = (int)blockIdx.x;
     int tm, tn, ksplit = 0;
-    if (SPLITK) {
+    if (XS) {
+        const int Tg = ((tiles_m + 7) / 8) * 8 * tiles_n;      // == gemm_grid(tiles_m, tiles_n)
+        const int rev = wg / Tg, wl = wg - rev * Tg;
+        ksplit = nsplit - 1 - rev;
+        const int g = wl / (8 * tiles_n), r = wl - g * 8 * tiles_n;
+        tm = g * 8 + (r & 7);
+        tn = r >> 3;
+        if (tm >= tiles_m) return;
+    } else if (SPLITK) {
         const int T = tiles_m * tiles_n;
         const int g = wg / (8 * T), r = wg - g * 8 * T;
         ksplit = g * 8 + (r & 7);
@@ -742,8 +758,8 @@ __global__ __launch_bounds__(256, SPH3D_SPLIT_DB ? 2 : 4) void gemm_split_mfma(i
         if (tm >= tiles_m) return;
     }
     const int m0 = tm * BMT, n0 = tn * BN;
-    const int k_begin = SPLITK ? ksplit * kchunk : 0;
-    const int k_end = SPLITK ? ((k_begin + kchunk) < Kd ? (k_begin + kchunk) : Kd) : Kd;
+    const int k_begin = (SPLITK || XS) ? ksplit * kchunk : 0;
+    const int k_end = (SPLITK || XS) ? ((k_begin + kchunk) < Kd ? (k_begin + kchunk) : Kd) : Kd;
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
     const int li = lane & 31, lk = lane >> 5;
@@ -834,6 +850,45 @@ __global__ __launch_bounds__(256, SPH3D_SPLIT_DB ? 2 : 4) void gemm_split_mfma(i
             __syncthreads();
         }
     }
+    if (XS) {
+        // The slabs and the counters are exchanged between workgroups on different XCDs (private L2s).  Every access to them is an
+        // agent-scope relaxed atomic (sc1: written through / read past the non-coherent cache lines), ordered by hand: the
+        // producer waits for its stores to be acknowledged (vmcnt) before it counts itself in; the consumer's slab loads are
+        // issued after it has seen the full count.  A release / acquire FENCE would be correct too and is 4x slower than not
+        // splitting at all: it writes back / invalidates the XCD's whole L2 (`buffer_wbl2` / `buffer_inv sc1`), once per
+        // workgroup, while the L2 is full of the dirty lines of the layer's operands (profiles/r06_exp_gemm_xs.log).
+        constexpr int NW = TM * TN * 16;                         // dwords per lane
+        const int tile = tm * tiles_n + tn, ntile = tiles_m * tiles_n;
+        if (ksplit > 0) {
+            float* sl = xslab + ((size_t)(ksplit - 1) * ntile + tile) * (NW * 256) + threadIdx.x;
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        __hip_atomic_store(&sl[((i * TN + j) * 16 + e) * 256], acc[i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(&xflag[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (threadIdx.x == 0) {
+            while (__hip_atomic_load(&xflag[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nsplit - 1) __builtin_amdgcn_s_sleep(4);
+            __hip_atomic_store(&xflag[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the buffer's invariant: counters are zero between launches
+        }
+        __syncthreads();
+        for (int ks = 1; ks < nsplit; ks++) {
+            const float* sl = xslab + ((size_t)(ks - 1) * ntile + tile) * (NW * 256) + threadIdx.x;
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        acc[i][j][e] += __hip_atomic_load(&sl[((i * TN + j) * 16 + e) * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     gemm_epilogue<BMT, BN, TM, TN, SPLITK, GUARD, STATS, EPX, LDSF>(acc, lds, M, N, Cmat, ldc, bias, act, stats, tm, ksplit, m0, n0, wave,
                                                                       lane, wm, wn, li, lk);
 }
@@ -887,6 +942,31 @@ static bool split_on()
     return g_split_mode != 0;
 }
 
+// In-kernel split-K exchange (gemm_split_mfma<..., XS>): splits per tile for a whole-tile product that would run as T 64 x 64 tiles
+// (grid Tg after XCD padding), 1 = do not split.  Up to ~1024 workgroups (4 per CU: all resident), at least 256 of k per split.
+// SPH3D_GEMM_XS: 0 off, n = at most n splits (experiments)
+static int xs_cap()
+{
+    static const int cap = getenv("SPH3D_GEMM_XS") ? atoi(getenv("SPH3D_GEMM_XS")) : 4;
+    return cap;
+}
+static int xs_splits(long long Tg, int Kd, int bk, int cap)
+{
+    int ns = (int)(1024 / (Tg > 0 ? Tg : 1));
+    if (Tg > 384) ns = 1;         // (512 tiles split in two: 22 vs 20 us at (2048, 512 -> 1024))
+    if (ns > cap) ns = cap;
+    while (ns > 1 && (Kd % (bk * ns) != 0 || Kd / ns < 256)) ns--;
+    return ns < 1 ? 1 : ns;
+}
+constexpr size_t kXsFlagBytes = 16384;      // 4096 arrival counters in front of the slabs
+// -> the exchange buffer of the stream (counters zero), or nullptr (capture in progress and nothing allocated yet / out of memory /
+// too many tiles): the caller then launches the ordinary kernel
+static char* xs_buffer(hipStream_t st, long long ntile, int nsplit, size_t tile_floats)
+{
+    if (ntile > (long long)(kXsFlagBytes / sizeof(int))) return nullptr;
+    return (char*)stream_scratch(st, kXsFlagBytes + sizeof(float) * (size_t)(nsplit - 1) * (size_t)ntile * tile_floats, 1);
+}
+
 template <bool AK, bool BKM, bool GUARD>
 static void launch_gemm_tiles(int M, int N, int Kd, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                               const float* bias, int act, hipStream_t st)
@@ -923,10 +1003,17 @@ static void launch_gemm_tiles(int M, int N, int Kd, const float* A, int lda, con
             else if (!BKM && N <= 64 && ntiles(128, 64) >= kMinTiles)
                 hipLaunchKernelGGL((gemm_split_mfma<AK, BKM, 128, 64, 16, false, false>), dim3(gemm_grid((M + 127) / 128, (N + 63) / 64)), dim3(256), 0,
                                    st, M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
-            else if (Kd % 32 == 0)
-                hipLaunchKernelGGL((gemm_split_mfma<AK, BKM, 64, 64, 32, false, false>), dim3(gemm_grid((M + 63) / 64, (N + 63) / 64)), dim3(256), 0,
-                                   st, M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
-            else
+            else if (Kd % 32 == 0) {
+                const long long Tg = gemm_grid(M / 64, N / 64);
+                const int ns = xs_splits(Tg, Kd, 32, xs_cap());
+                char* xb = ns > 1 ? xs_buffer(st, (long long)(M / 64) * (N / 64), ns, 64 * 64) : nullptr;
+                if (xb != nullptr)
+                    hipLaunchKernelGGL((gemm_split_mfma<AK, BKM, 64, 64, 32, false, false, false, true>), dim3((unsigned)(Tg * ns)), dim3(256), 0, st,
+                                       M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, Kd / ns, nullptr, ns, (float*)(xb + kXsFlagBytes), (int*)xb);
+                else
+                    hipLaunchKernelGGL((gemm_split_mfma<AK, BKM, 64, 64, 32, false, false>), dim3(gemm_grid((M + 63) / 64, (N + 63) / 64)), dim3(256), 0,
+                                       st, M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
+            } else
                 hipLaunchKernelGGL((gemm_split_mfma<AK, BKM, 64, 64, 16, false, false>), dim3(gemm_grid((M + 63) / 64, (N + 63) / 64)), dim3(256), 0,
                                    st, M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, 0);
             return;
@@ -1050,10 +1137,16 @@ extern "C" int sph3d_pointwise_gemm_bnstats(int R, int Cin, int Cout, const floa
         else if (bm == 128)
             hipLaunchKernelGGL((gemm_split_mfma<true, false, 128, 64, 16, false, true>), dim3(tiles), dim3(256), 0, st, R, Cout, Cin, X, Cin, W,
                                Cout, Y, Cout, bias, 0, 0, partial);
-        else if (Cin % 32 == 0)
-            hipLaunchKernelGGL((gemm_split_mfma<true, false, 64, 64, 32, false, true>), dim3(tiles), dim3(256), 0, st, R, Cout, Cin, X, Cin, W,
-                               Cout, Y, Cout, bias, 0, 0, partial);
-        else
+        else if (Cin % 32 == 0) {
+            const int ns = xs_splits(tiles, Cin, 32, xs_cap());
+            char* xb = ns > 1 ? xs_buffer(st, (long long)(R / 64) * (Cout / 64), ns, 64 * 64) : nullptr;
+            if (xb != nullptr)
+                hipLaunchKernelGGL((gemm_split_mfma<true, false, 64, 64, 32, false, true, false, true>), dim3(tiles * ns), dim3(256), 0, st, R, Cout,
+                                   Cin, X, Cin, W, Cout, Y, Cout, bias, 0, Cin / ns, partial, ns, (float*)(xb + kXsFlagBytes), (int*)xb);
+            else
+                hipLaunchKernelGGL((gemm_split_mfma<true, false, 64, 64, 32, false, true>), dim3(tiles), dim3(256), 0, st, R, Cout, Cin, X, Cin, W,
+                                   Cout, Y, Cout, bias, 0, 0, partial);
+        } else
             hipLaunchKernelGGL((gemm_split_mfma<true, false, 64, 64, 16, false, true>), dim3(tiles), dim3(256), 0, st, R, Cout, Cin, X, Cin, W,
                                Cout, Y, Cout, bias, 0, 0, partial);
         return check_launch("sph3d_pointwise_gemm_bnstats");
@@ -1100,6 +1193,21 @@ extern "C" int sph3d_pointwise_gemm_tn(int R, int Cin, int Cout, const float* X,
                        Cin, dY, Cout, out, Cout, nullptr, 0, kchunk, nullptr, nsplit)
     // whole tiles: BK = 16 at four workgroups per CU (8 + 8 prefetch registers with the 2x4 transposing units): 0.786 vs
     // 0.855 ms over the step's shapes against BK = 32 at two per CU
+    // short products (few rows of k, many output tiles): 64 x 64 tiles with the in-kernel exchange — up to 8 splits whose slabs are
+    // 16 KB — instead of 128 x 128 tiles + slab-sum launch.  (The exchange with 128 x 128 tiles and 8-16 splits was measured and is
+    // SLOWER than the slab-sum kernel: 72 vs 38, 82 vs 50, 84 vs 62 us — split 0 reads 7-15 64-KB slabs past the cache, one dword per
+    // lane and instruction; profiles/r06_exp_gemm_xs.log.)  SPH3D_GEMM_TN_XS: largest R that takes this path (experiments)
+    static const int tn_xs_rows = getenv("SPH3D_GEMM_TN_XS") ? atoi(getenv("SPH3D_GEMM_TN_XS")) : 2048;
+    if (split_on() && R <= tn_xs_rows && Cin % 64 == 0 && Cout % 64 == 0 && R % 32 == 0 && aligned16(X) && aligned16(dY) && aligned16(dW)) {
+        const long long Tg = gemm_grid(Cin / 64, Cout / 64);
+        const int ns = xs_splits(Tg, R, 32, 8);
+        char* xb = ns > 1 ? xs_buffer(st, (long long)(Cin / 64) * (Cout / 64), ns, 64 * 64) : nullptr;
+        if (xb != nullptr) {
+            hipLaunchKernelGGL((gemm_split_mfma<false, false, 64, 64, 32, false, false, false, true>), dim3((unsigned)(Tg * ns)), dim3(256), 0, st, Cin,
+                               Cout, R, X, Cin, dY, Cout, dW, Cout, nullptr, 0, R / ns, nullptr, ns, (float*)(xb + kXsFlagBytes), (int*)xb);
+            return check_launch("sph3d_pointwise_gemm_tn");
+        }
+    }
     if (whole && split_on()) {
         if (bn == 128)
             hipLaunchKernelGGL((gemm_split_mfma<false, false, 128, 128, 16, true, false>), dim3(gemm_grid(tiles, 1, nsplit)), dim3(256), 0, st, Cin,

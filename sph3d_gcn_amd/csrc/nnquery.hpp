@@ -71,9 +71,5 @@ int nngrid_search(int B, int N, int M, int K, float radius, int fixed, const flo
                   void* workspace, size_t workspace_bytes, bool library_scratch);
 size_t nngrid_workspace_bytes(int B, int N, int M);
 
-// api.cpp: a library-owned device buffer of at least `bytes` for work queued on `stream` of the current device (one per
-// (device, stream), grown on demand and kept; nullptr if the allocation fails or the stream is being captured).  Only for
-// state that is dead when the call's last kernel has run.
-void* stream_scratch(hipStream_t stream, size_t bytes);
 
 }  // namespace sph3d

@@ -8,12 +8,17 @@ import torch
 import torch.distributed as dist
 
 
+FORCE_COLLECTIVES = os.environ.get("SPH3D_FORCE_COLLECTIVES", "0") == "1"
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # SPH3D_FORCE_COLLECTIVES=1: create the group and issue the gradient buckets' all-reduces at world size 1 too — the only way
+    # to run the RCCL path (communicator, its stream, the event ordering of FlatGradAllReduce) on a one-GPU box
+    if (world > 1 or FORCE_COLLECTIVES) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -184,7 +189,7 @@ class FlatGradAllReduce:
             w = self._collective(view)
             if w is not None:
                 self._pending.append(w)
-        elif self._world() > 1:
+        elif self._world() > 1 or (FORCE_COLLECTIVES and dist.is_initialized()):
             self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
         self.stats["buckets_started_in_backward" if self._armed else "buckets_started_after_backward"] += 1
         self._done.add(bi)
@@ -202,7 +207,7 @@ class FlatGradAllReduce:
         return hook
 
     def broadcast_params(self, src=0):
-        if self._world() > 1:
+        if self._world() > 1 or (FORCE_COLLECTIVES and dist.is_initialized()):
             dist.broadcast(self.flat_param.data, src=src)
 
     def zero(self):

@@ -25,6 +25,31 @@ def test_bench_self_launch_two_ranks():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["value"] > 0
 
 
+def test_bench_under_torchrun_runs_the_rccl_path_on_one_gpu():
+    """One rank under torch.distributed.run with SPH3D_FORCE_COLLECTIVES=1: the process group is RCCL, every gradient bucket's
+    all-reduce is issued during the backward pass on RCCL's stream and waited for before Adam (at world size 1 the sum is the
+    identity, so the loss must equal the plain run's) — what a one-GPU box can check of the multi-rank path"""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["SPH3D_FORCE_COLLECTIVES"] = "1"
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-probes"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["config"]["collective_backend"] == "nccl" and out["config"]["world_size"] == 1
+    assert out["dist"]["buckets_started_in_backward"] > 0 and out["dist"]["buckets_started_after_backward"] == 0
+    assert out["value"] > 0 and out["loss"] == out["loss"]
+    env.pop("SPH3D_FORCE_COLLECTIVES")
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-probes"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert q.returncode == 0, q.stdout[-2000:] + q.stderr[-2000:]
+    plain = json.loads([l for l in q.stdout.splitlines() if l.startswith("{")][-1])
+    assert abs(plain["loss"] - out["loss"]) <= 1e-3 * abs(plain["loss"])
+
+
 def test_bench_single_gpu_line_has_the_contract_fields():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=900)

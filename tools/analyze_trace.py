@@ -7,7 +7,7 @@ ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), r
 ev.sort()
 # steady-state window: one fps_reg_kernel<8> launch per training step; steps 20..28 of the run lie inside bench.py's
 # timed region (16 priming + 2 warm-up steps come first)
-marks = [e[0] for e in ev if "fps_reg_kernel<8>" in e[3]]
+marks = [e[0] for e in ev if "fps_prune_kernel" in e[3] or "fps_reg_kernel<8>" in e[3]]
 lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (20, 28)
 nsteps = hi - lo
 ev = [e for e in ev if marks[lo] <= e[0] < marks[hi]]
