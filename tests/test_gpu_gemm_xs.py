@@ -72,3 +72,41 @@ def test_exchange_interleaved_shapes_and_streams(dev):
         assert torch.equal(y, ref[1 if second else 0][0]) and torch.equal(dw, ref[1 if second else 0][1])
     assert _lib.lib().sph3d_release_stream_scratch(s1.cuda_stream) >= 1          # the streams' exchange buffers (library-owned)
     assert _lib.lib().sph3d_release_stream_scratch(s2.cuda_stream) >= 1
+
+
+def test_exchange_under_stream_capture(dev):
+    """no allocation under capture: on a stream that has no exchange buffer yet the ordinary kernel is captured (same values within the
+    products' rounding); on a stream whose buffer exists the exchange kernel is captured and its counters are back at zero after
+    every replay (bit-equal replays, bit-equal to the eager call)"""
+    l = _lib.lib()
+    R, Ci, Co = 2048, 1024, 512
+    x, w, _ = _ops(dev, R, Ci, Co, 11)
+    want = (x.double() @ w.double())
+    mag = x.double().abs() @ w.double().abs()
+
+    def capture(stream, y):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(stream):
+            with torch.cuda.graph(g, stream=stream):
+                rc = l.sph3d_pointwise_gemm(R, Ci, Co, _lib.ptr(x), _lib.ptr(w), None, 0, 0, _lib.ptr(y), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        return g
+
+    fresh = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    y0 = torch.zeros(R, Co, device=dev)
+    g0 = capture(fresh, y0)                              # no buffer on this stream: nothing may be allocated now
+    g0.replay(); torch.cuda.synchronize()
+    assert float(((y0.double() - want).abs() / mag).max()) <= 4e-7
+    warm = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(warm):
+        eager = tf_gemm._pointwise_gemm_impl(x, w, False)  # allocates the stream's buffer
+    torch.cuda.synchronize()
+    y1 = torch.zeros(R, Co, device=dev)
+    g1 = capture(warm, y1)
+    for _ in range(3):
+        y1.zero_()
+        g1.replay(); torch.cuda.synchronize()
+        assert torch.equal(y1, eager)
+    l.sph3d_release_stream_scratch(fresh.cuda_stream)
+    l.sph3d_release_stream_scratch(warm.cuda_stream)
