@@ -110,3 +110,13 @@ def test_exchange_under_stream_capture(dev):
         assert torch.equal(y1, eager)
     l.sph3d_release_stream_scratch(fresh.cuda_stream)
     l.sph3d_release_stream_scratch(warm.cuda_stream)
+
+
+def test_exchange_with_bias_and_elu_epilogue(dev):
+    R, Ci, Co = 2048, 1024, 512
+    x, w, _ = _ops(dev, R, Ci, Co, 5)
+    bias = torch.randn(Co, device=dev)
+    y = tf_gemm._gemm_bias_act_impl(x, w, bias, 1)
+    want = torch.nn.functional.elu(x.double() @ w.double() + bias.double())
+    torch.testing.assert_close(y.double(), want, rtol=1e-5, atol=2e-5)
+    assert torch.equal(tf_gemm._gemm_bias_act_impl(x, w, bias, 1), y)
