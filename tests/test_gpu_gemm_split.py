@@ -97,3 +97,20 @@ def test_split_non_finite_operands_never_give_finite_outputs(dev, modes):
     y = tf_gemm._pointwise_gemm_impl(x, w, False)
     assert not torch.isfinite(y[5]).any() and not torch.isfinite(y[9]).any()
     assert torch.isfinite(y[torch.tensor([0, 1, 2, 3, 4, 6, 7, 8, 10], device=dev)]).all()
+
+
+def test_split_products_scale_exactly_by_powers_of_two_at_full_size(dev, modes):
+    """size-independent property at the bench's level-0 shape: x = h + m + l is cut by truncation, so 2^k x cuts into 2^k h, 2^k m,
+    2^k l and every partial product and fp32 accumulation scales exactly — the products of scaled operands are the scaled products,
+    bit for bit (NN, NT, TN incl. the split-K slab sum)"""
+    modes.sph3d_pointwise_gemm_mode(1)
+    R, Ci, Co = 131072, 256, 128
+    g = torch.Generator(device=dev).manual_seed(17)
+    x = torch.randn(R, Ci, device=dev, generator=g)
+    w = torch.randn(Ci, Co, device=dev, generator=g) / 16
+    dy = torch.randn(R, Co, device=dev, generator=g)
+    y, dx, dw = _products(x, w, dy)
+    y2, dx2, dw2 = _products(x * 8.0, w * 0.25, dy * 8.0)
+    assert torch.equal(y2, y * 2.0)
+    assert torch.equal(dx2, dx * 2.0)
+    assert torch.equal(dw2, dw * 64.0)
