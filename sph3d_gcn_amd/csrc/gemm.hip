@@ -952,8 +952,10 @@ static int xs_cap()
 }
 static int xs_splits(long long Tg, int Kd, int bk, int cap)
 {
-    int ns = (int)(1024 / (Tg > 0 ? Tg : 1));
-    if (Tg > 384) ns = 1;         // (512 tiles split in two: 22 vs 20 us at (2048, 512 -> 1024))
+    static const int max_wgs = getenv("SPH3D_GEMM_XS_WGS") ? atoi(getenv("SPH3D_GEMM_XS_WGS")) : 1024;      // (experiments)
+    static const int max_tg = getenv("SPH3D_GEMM_XS_TG") ? atoi(getenv("SPH3D_GEMM_XS_TG")) : 384;
+    int ns = (int)(max_wgs / (Tg > 0 ? Tg : 1));
+    if (Tg > max_tg) ns = 1;      // (512 tiles split in two: 22 vs 20 us at (2048, 512 -> 1024))
     if (ns > cap) ns = cap;
     while (ns > 1 && (Kd % (bk * ns) != 0 || Kd / ns < 256)) ns--;
     return ns < 1 ? 1 : ns;
