@@ -345,6 +345,10 @@ int sph3d_pointwise_gemm(int R, int Cin, int Cout,
  *      accumulated in fp32 (csrc/gemm.hip: gemm_split_mfma) — fp32-sized error (<= 2^-23 per product), 2.7x the fp32 MFMA rate;
  *   0: v_mfma_f32_32x32x2_f32, a k-ordered fp32 fmaf chain (what ragged shapes always take);  other values: query only. */
 int sph3d_pointwise_gemm_mode(int mode);
+/* Products whose tile grid is too small to fill the chip run several workgroups per tile that exchange their partial accumulators inside
+ * the launch (csrc/gemm.hip); the waiting workgroup's spin is bounded.  -> number of launches that ever gave up waiting
+ * (never expected: 0; synchronises with the device; -1 if the counter cannot be read). */
+int sph3d_pointwise_gemm_exchange_failures(void);
 int sph3d_pointwise_gemm_tn(int R, int Cin, int Cout,
                             const float* X, const float* dY, float* dW,
                             void* workspace, size_t workspace_bytes,

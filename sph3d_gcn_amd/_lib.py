@@ -88,6 +88,7 @@ SIGNATURES = {
     "sph3d_separable_conv3d_train_blocks": (_I, [_I]),
     "sph3d_separable_conv3d_train": (_I, [_I] * 8 + [_P] * 11),
     "sph3d_separable_conv3d_ring_failures": (_I, []),
+    "sph3d_pointwise_gemm_exchange_failures": (_I, []),
     "sph3d_elu_bn_forward_partials": (_I, [_I] * 3 + [_P] * 6 + [_F, _F] + [_P] * 4),
     "sph3d_elu_bn_forward": (_I, [_I, _I, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _S, _P]),
     "sph3d_elu_bn_backward": (_I, [_I, _I] + [_P] * 5 + [_I] + [_P] * 3 + [_P, _S, _P]),

@@ -705,6 +705,8 @@ struct SplitStage {
 #ifndef SPH3D_SPLIT_DB
 #define SPH3D_SPLIT_DB 0      // 1: two plane images (one barrier per k-tile, 3 workgroups per CU at 128 x 128); 0: one image, two barriers, 4-5 per CU
 #endif
+__device__ int g_xs_fail = 0;      // exchange launches that gave up waiting (never expected)
+
 // XS (in-kernel split-K exchange, for products whose tile grid is too small to fill the chip and whose k loop is long): the grid holds
 // `nsplit` workgroups per tile, each multiplying `kchunk` of k.  Splits 1 .. nsplit-1 (the LOWER workgroup ids: dispatched first,
 // they never wait) store their accumulators — in register layout, 16 contiguous bytes per lane — to their slab of `xslab`, fence,
@@ -874,7 +876,16 @@ __global__ __launch_bounds__(256, SPH3D_SPLIT_DB ? 2 : 4) void gemm_split_mfma(i
             return;
         }
         if (threadIdx.x == 0) {
-            while (__hip_atomic_load(&xflag[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nsplit - 1) __builtin_amdgcn_s_sleep(4);
+            // bounded: the producers are dispatched first and never wait, so the count always arrives; a launch that would still
+            // spin after ~1 s (a fault elsewhere) gives up, counts the failure (sph3d_pointwise_gemm_exchange_failures) and ends
+            int polls = 0;
+            while (__hip_atomic_load(&xflag[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nsplit - 1) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++polls > (1 << 20)) {
+                    atomicAdd(&g_xs_fail, 1);
+                    break;
+                }
+            }
             __hip_atomic_store(&xflag[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the buffer's invariant: counters are zero between launches
         }
         __syncthreads();
@@ -1094,6 +1105,13 @@ static void tn_plan(int R, int Cin, int Cout, int& bn, int& tiles, int& nsplit, 
 }  // namespace sph3d
 
 using namespace sph3d;
+
+extern "C" int sph3d_pointwise_gemm_exchange_failures(void)
+{
+    int v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_xs_fail), sizeof(int), 0, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v;
+}
 
 extern "C" int sph3d_pointwise_gemm_mode(int mode)
 {

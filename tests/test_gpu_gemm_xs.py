@@ -70,6 +70,7 @@ def test_exchange_interleaved_shapes_and_streams(dev):
     torch.cuda.synchronize()
     for second, y, dw in outs:
         assert torch.equal(y, ref[1 if second else 0][0]) and torch.equal(dw, ref[1 if second else 0][1])
+    assert _lib.lib().sph3d_pointwise_gemm_exchange_failures() == 0              # no launch ever gave up waiting
     assert _lib.lib().sph3d_release_stream_scratch(s1.cuda_stream) >= 1          # the streams' exchange buffers (library-owned)
     assert _lib.lib().sph3d_release_stream_scratch(s2.cuda_stream) >= 1
 
